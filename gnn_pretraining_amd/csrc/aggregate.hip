@@ -1,0 +1,232 @@
+// Segmented neighbour gather + sum over CSR rows (GIN aggregation, mean pooling,
+// scatter-add backward of row gathers).
+//
+// Mapping for CDNA4: one 64-lane wave owns a destination row; lane l holds float4
+// #l of the row, so a 256-wide fp32 row is exactly ONE global_load_dwordx4 wave
+// instruction (1 KiB, fully coalesced).  Neighbour ids are fetched 64 at a time
+// with one coalesced load and handed out with v_readlane (wave-uniform row base in
+// SGPRs).  Each wave walks a contiguous chunk of rows and the block->chunk map
+// gives every XCD one contiguous span of the row space, so the neighbour rows of a
+// graph (which sit next to each other in the batch) are re-read from that XCD's
+// own L2 instead of crossing to HBM again.  HBM-bound: compulsory traffic is
+// read x once + write out once.
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int BLOCK = 256;                     // 4 waves
+constexpr int WAVES_PER_BLOCK = BLOCK / GMP_WAVE;
+constexpr int NUM_XCD = 8;
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
+    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// NV = float4 per lane (F <= 256*NV).  SELF: out = scale*self + sum.  DOT: also
+// accumulate <self[r], dotx[r]> per block into dot_partials[blockIdx] (eps gradient).
+template <int NV, bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT>
+__global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict__ src, const int* __restrict__ ptr,
+                                                        const int* __restrict__ idx, const float4* __restrict__ self,
+                                                        const float* __restrict__ eps, const float4* __restrict__ dotx,
+                                                        float4* __restrict__ out, float* __restrict__ dot_partials,
+                                                        int64_t nrows, int F4, int rows_per_wave) {
+    // XCD-aware: hardware deals blocks round-robin over 8 XCDs; give XCD k the k-th
+    // contiguous eighth of the chunk space (gridDim.x is a multiple of 8).
+    const int per_xcd = gridDim.x / NUM_XCD;
+    const int lb = (blockIdx.x % NUM_XCD) * per_xcd + blockIdx.x / NUM_XCD;
+    const int lane = threadIdx.x % GMP_WAVE, wv = threadIdx.x / GMP_WAVE;
+    const int64_t gw = (int64_t)lb * WAVES_PER_BLOCK + wv;
+    int64_t r0 = gw * rows_per_wave;
+    int64_t r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    float scale = 1.f;
+    if (SELF) scale = 1.f + (eps ? eps[0] : 0.f);
+    float dot = 0.f;
+    bool act[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) act[v] = lane + v * GMP_WAVE < F4;
+
+    for (int64_t r = r0; r < r1; ++r) {
+        const int start = __builtin_amdgcn_readfirstlane(ptr[r]);
+        const int end = __builtin_amdgcn_readfirstlane(ptr[r + 1]);
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (SELF) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (act[v]) {
+                    float4 s = self[r * F4 + lane + v * GMP_WAVE];
+                    if (DOT) dot += f4dot(s, dotx[r * F4 + lane + v * GMP_WAVE]);
+                    acc[v] = make_float4(scale * s.x, scale * s.y, scale * s.z, scale * s.w);
+                }
+        }
+        for (int e = start; e < end; e += GMP_WAVE) {
+            const int cnt = end - e < GMP_WAVE ? end - e : GMP_WAVE;
+            int mine = e + lane;
+            if (IDX) mine = lane < cnt ? idx[e + lane] : 0;
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {   // 4 independent row loads in flight per wave
+                const int64_t c0 = __builtin_amdgcn_readlane(mine, j), c1 = __builtin_amdgcn_readlane(mine, j + 1);
+                const int64_t c2 = __builtin_amdgcn_readlane(mine, j + 2), c3 = __builtin_amdgcn_readlane(mine, j + 3);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (act[v]) {
+                        const int o = lane + v * GMP_WAVE;
+                        float4 a = src[c0 * F4 + o], b = src[c1 * F4 + o], c = src[c2 * F4 + o], d = src[c3 * F4 + o];
+                        acc[v] = f4add(f4add(f4add(f4add(acc[v], a), b), c), d);
+                    }
+            }
+            for (; j < cnt; ++j) {
+                const int64_t c0 = __builtin_amdgcn_readlane(mine, j);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (act[v]) acc[v] = f4add(acc[v], src[c0 * F4 + lane + v * GMP_WAVE]);
+            }
+        }
+        float m = 1.f;
+        if (MEAN) {
+            int c = end - start;
+            m = 1.f / (float)(c > 1 ? c : 1);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (act[v]) {
+                float4 a = acc[v];
+                if (MEAN) a = make_float4(a.x * m, a.y * m, a.z * m, a.w * m);
+                const int64_t o = r * F4 + lane + v * GMP_WAVE;
+                if (ACCUM) a = f4add(out[o], a);
+                out[o] = a;
+            }
+    }
+    if (DOT) {
+        __shared__ float wsum[WAVES_PER_BLOCK];
+        dot = gmp::wave_sum(dot);
+        if (lane == 0) wsum[wv] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int i = 0; i < WAVES_PER_BLOCK; ++i) s += wsum[i];
+            dot_partials[lb] = s;   // logical block id: fixed summation order in the final pass
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ p, int n, float* out) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+struct Plan {
+    int grid, rows_per_wave;
+};
+
+// Enough waves to fill 256 CUs x 8 waves/SIMD (8192 waves), chunks of >= 1 row;
+// larger inputs get longer chunks instead of more blocks (grid-stride by chunk).
+Plan make_plan(int64_t nrows) {
+    const int64_t target_waves = 256 * 32;
+    int64_t rpw = (nrows + target_waves - 1) / target_waves;
+    if (rpw < 1) rpw = 1;
+    int64_t waves = (nrows + rpw - 1) / rpw;
+    int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    blocks = (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
+    if (blocks < NUM_XCD) blocks = NUM_XCD;
+    return Plan{(int)blocks, (int)rpw};
+}
+
+template <bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT>
+int launch_nv(int nv, const Plan& p, hipStream_t st, const float* src, const int* ptr, const int* idx,
+              const float* self, const float* eps, const float* dotx, float* out, float* partials, int64_t nrows,
+              int F4) {
+#define GMP_LAUNCH_NV(NV)                                                                                       \
+    hipLaunchKernelGGL((seg_sum_kernel<NV, SELF, IDX, MEAN, ACCUM, DOT>), dim3(p.grid), dim3(BLOCK), 0, st,    \
+                       (const float4*)src, ptr, idx, (const float4*)self, eps, (const float4*)dotx, (float4*)out, \
+                       partials, nrows, F4, p.rows_per_wave)
+    switch (nv) {
+        case 1: GMP_LAUNCH_NV(1); break;
+        case 2: GMP_LAUNCH_NV(2); break;
+        case 3: GMP_LAUNCH_NV(3); break;
+        case 4: GMP_LAUNCH_NV(4); break;
+        default: return gmp::fail(GMP_ERR_UNSUPPORTED, "feature width %d > 1024", F4 * 4);
+    }
+#undef GMP_LAUNCH_NV
+    return gmp::check_launch("seg_sum_kernel");
+}
+
+int check_feat(const char* who, int feat) {
+    if (feat <= 0 || feat % 4 != 0 || feat > 1024)
+        return gmp::fail(GMP_ERR_ARG, "%s: feature width %d must be a multiple of 4 in [4,1024]", who, feat);
+    return GMP_OK;
+}
+
+}  // namespace
+
+extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, const int32_t* col, const float* eps,
+                                     float* out, int64_t N, int feat, gmp_stream_t stream) {
+    if (int rc = check_feat("gin_aggregate_fwd", feat)) return rc;
+    if (N < 0 || (N > 0 && (!x || !rowptr || !out))) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd: null pointer");
+    if (N == 0) return GMP_OK;
+    const int F4 = feat / 4;
+    Plan p = make_plan(N);
+    return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, (hipStream_t)stream, x, rowptr, col, x, eps,
+                                                      nullptr, out, nullptr, N, F4);
+}
+
+extern "C" size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t N, int feat) {
+    (void)feat;
+    return (size_t)make_plan(N > 0 ? N : 1).grid * sizeof(float) + 256;
+}
+
+extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t,
+                                     const float* eps, const float* x, float* g_x, float* g_eps, int64_t N, int feat,
+                                     void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    if (int rc = check_feat("gin_aggregate_bwd", feat)) return rc;
+    if (N < 0 || (N > 0 && (!g_out || !rowptr_t || !g_x)))
+        return gmp::fail(GMP_ERR_ARG, "gin_aggregate_bwd: null pointer");
+    if (g_eps && !x) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_bwd: g_eps needs x");
+    const int F4 = feat / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        if (g_eps) hipMemsetAsync(g_eps, 0, sizeof(float), st);
+        return GMP_OK;
+    }
+    Plan p = make_plan(N);
+    if (!g_eps)
+        return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, st, g_out, rowptr_t, col_t, g_out, eps,
+                                                          nullptr, g_x, nullptr, N, F4);
+    if (ws_bytes < (size_t)p.grid * sizeof(float)) return gmp::fail(GMP_ERR_WORKSPACE, "gin_aggregate_bwd: workspace");
+    int rc = launch_nv<true, true, false, false, true>((F4 + 63) / 64, p, st, g_out, rowptr_t, col_t, g_out, eps, x, g_x,
+                                                       (float*)ws, N, F4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, p.grid, g_eps);
+    return gmp::check_launch("reduce_partials_kernel");
+}
+
+extern "C" int gmp_segment_sum(const float* src, const int32_t* ptr, const int32_t* idx, float* out, int64_t nseg,
+                               int feat, int mean, int accumulate, gmp_stream_t stream) {
+    if (int rc = check_feat("segment_sum", feat)) return rc;
+    if (nseg < 0 || (nseg > 0 && (!src || !ptr || !out))) return gmp::fail(GMP_ERR_ARG, "segment_sum: null pointer");
+    if (nseg == 0) return GMP_OK;
+    const int F4 = feat / 4, nv = (F4 + 63) / 64;
+    Plan p = make_plan(nseg);
+    hipStream_t st = (hipStream_t)stream;
+#define GMP_SS(IDX, MEAN, ACC) \
+    return launch_nv<false, IDX, MEAN, ACC, false>(nv, p, st, src, ptr, idx, nullptr, nullptr, nullptr, out, nullptr, nseg, F4)
+    if (idx) {
+        if (mean) { if (accumulate) GMP_SS(true, true, true); else GMP_SS(true, true, false); }
+        else      { if (accumulate) GMP_SS(true, false, true); else GMP_SS(true, false, false); }
+    } else {
+        if (mean) { if (accumulate) GMP_SS(false, true, true); else GMP_SS(false, true, false); }
+        else      { if (accumulate) GMP_SS(false, false, true); else GMP_SS(false, false, false); }
+    }
+#undef GMP_SS
+}

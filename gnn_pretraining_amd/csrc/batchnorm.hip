@@ -1,0 +1,435 @@
+// Segment-wise BatchNorm1d fused with residual add, ReLU and dropout.
+//
+// A "segment" = the rows of one reference forward() call, so several independent
+// forwards (7 per domain per step in the s4 scheme) share a launch while keeping
+// their own batch statistics.  Two regimes, picked from the longest segment:
+//   short segments (<= SHORT_MAX rows): one workgroup owns (segment, 64 columns),
+//     walks the rows three times out of L2 (mean, centred variance, apply) -- exact
+//     two-pass statistics, no atomics, one launch;
+//   long segments (Cora, the roofline ladder): row chunks produce (mean, M2)
+//     partials, combined in chunk order with Chan's formula, then an apply pass.
+// Both are deterministic.  Memory-bound; a thread moves float4.
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int COLS = 64;          // columns per block
+constexpr int CQ = COLS / 4;      // float4 column quads per block (16)
+constexpr int RL = THREADS / CQ;  // row lanes per block (16)
+constexpr int SHORT_MAX = 512;
+constexpr int CHUNK = 256;        // rows per chunk in the long regime
+
+struct BnArgs {
+    const float* x;
+    const float* res;
+    const float* gy;
+    const int* seg_ptr;
+    int S;
+    int C;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* save_mean;
+    float* save_rstd;
+    float* y;       // fwd: output; bwd: g_u
+    float* part;    // long regime: chunk partials
+    float* segsum;  // bwd: [S][2][C] (sum g, sum g*xhat)
+    int chunks;     // chunks per segment (long regime)
+    gmp_bn_config cfg;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// reduce a float4 over the RL row lanes of the block (same column quad); result to all
+__device__ __forceinline__ float4 block_colsum(float4 v, float4 (*sh)[CQ], int rl, int cq) {
+    __syncthreads();
+    sh[rl][cq] = v;
+    __syncthreads();
+    float4 s = sh[0][cq];
+#pragma unroll
+    for (int i = 1; i < RL; ++i) s = add4(s, sh[i][cq]);
+    return s;
+}
+
+__device__ __forceinline__ float4 load_u(const BnArgs& a, int64_t off) {
+    float4 u = ld4(a.x + off);
+    if (a.res) u = add4(u, ld4(a.res + off));
+    return u;
+}
+
+// y = dropout(relu(gamma*xhat+beta)) for one float4; returns the pre-dropout activation mask in `pos`
+__device__ __forceinline__ float4 bn_apply(const BnArgs& a, float4 u, float4 mean, float4 rstd, float4 gam, float4 bet,
+                                           int64_t elem_quad, float4* gate) {
+    float4 xh = mul4(sub4(u, mean), rstd);
+    float4 y = make_float4(fmaf(gam.x, xh.x, bet.x), fmaf(gam.y, xh.y, bet.y), fmaf(gam.z, xh.z, bet.z), fmaf(gam.w, xh.w, bet.w));
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.cfg.relu) {
+        g = make_float4(y.x > 0.f, y.y > 0.f, y.z > 0.f, y.w > 0.f);
+        y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
+    }
+    if (a.cfg.dropout_p > 0.f) {
+        float4 d = gmp::dropout_scale4(a.cfg.seed, a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p,
+                                       1.f / (1.f - a.cfg.dropout_p));
+        y = mul4(y, d);
+        g = mul4(g, d);
+    }
+    *gate = g;
+    return y;
+}
+
+__device__ __forceinline__ void stats_for(const BnArgs& a, int s, int c, float4* mean, float4* rstd) {
+    if (a.cfg.training) {
+        *mean = ld4(a.save_mean + (int64_t)s * a.C + c);
+        *rstd = ld4(a.save_rstd + (int64_t)s * a.C + c);
+    } else {
+        *mean = ld4(a.running_mean + c);
+        float4 v = ld4(a.running_var + c);
+        *rstd = make_float4(rsqrtf(v.x + a.cfg.eps), rsqrtf(v.y + a.cfg.eps), rsqrtf(v.z + a.cfg.eps), rsqrtf(v.w + a.cfg.eps));
+    }
+}
+
+// ------------------------------------------------------------ short regime, fwd
+__global__ __launch_bounds__(THREADS) void bn_fwd_short_kernel(BnArgs a) {
+    __shared__ float4 sh[RL][CQ];
+    const int s = blockIdx.x, cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int c = blockIdx.y * COLS + cq * 4;
+    const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
+    if (n <= 0) return;
+    float4 mean, rstd;
+    if (a.cfg.training) {
+        float4 acc = zero4();
+        for (int r = r0 + rl; r < r1; r += RL) acc = add4(acc, load_u(a, (int64_t)r * a.C + c));
+        mean = scl4(block_colsum(acc, sh, rl, cq), 1.f / n);
+        acc = zero4();
+        for (int r = r0 + rl; r < r1; r += RL) {
+            float4 d = sub4(load_u(a, (int64_t)r * a.C + c), mean);
+            acc = add4(acc, mul4(d, d));
+        }
+        float4 var = scl4(block_colsum(acc, sh, rl, cq), 1.f / n);
+        rstd = make_float4(rsqrtf(var.x + a.cfg.eps), rsqrtf(var.y + a.cfg.eps), rsqrtf(var.z + a.cfg.eps), rsqrtf(var.w + a.cfg.eps));
+        if (rl == 0) {
+            st4(a.save_mean + (int64_t)s * a.C + c, mean);
+            st4(a.save_rstd + (int64_t)s * a.C + c, rstd);
+        }
+    } else {
+        stats_for(a, s, c, &mean, &rstd);
+    }
+    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int64_t off = (int64_t)r * a.C + c;
+        float4 gate;
+        st4(a.y + off, bn_apply(a, load_u(a, off), mean, rstd, gam, bet, off >> 2, &gate));
+    }
+}
+
+// running statistics: segments applied in order, exactly like S successive forward() calls
+__global__ __launch_bounds__(THREADS) void bn_running_kernel(BnArgs a) {
+    const int c = blockIdx.x * THREADS + threadIdx.x;
+    if (c >= a.C) return;
+    float rm = a.running_mean[c], rv = a.running_var[c];
+    const float m = a.cfg.momentum;
+    for (int s = 0; s < a.S; ++s) {
+        const int n = a.seg_ptr[s + 1] - a.seg_ptr[s];
+        if (n <= 0) continue;
+        const float mean = a.save_mean[(int64_t)s * a.C + c], rstd = a.save_rstd[(int64_t)s * a.C + c];
+        const float var = 1.f / (rstd * rstd) - a.cfg.eps;   // biased batch variance
+        const float unb = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+        rm = (1.f - m) * rm + m * mean;
+        rv = (1.f - m) * rv + m * unb;
+    }
+    a.running_mean[c] = rm;
+    a.running_var[c] = rv;
+}
+
+// ------------------------------------------------------------- long regime, fwd
+// partial layout: part[((s*chunks + j)*2 + {0:mean,1:M2}) * C + c]
+__global__ __launch_bounds__(THREADS) void bn_partial_kernel(BnArgs a) {
+    __shared__ float4 sh[RL][CQ];
+    const int s = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = blockIdx.y * COLS + cq * 4;
+    const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1];
+    const int r0 = seg0 + j * CHUNK, r1 = min(r0 + CHUNK, seg1);
+    if (r0 >= seg1) return;   // block-uniform
+    const int n = r1 - r0;
+    float4 acc = zero4();
+    for (int r = r0 + rl; r < r1; r += RL) acc = add4(acc, load_u(a, (int64_t)r * a.C + c));
+    const float4 mean = scl4(block_colsum(acc, sh, rl, cq), 1.f / n);
+    acc = zero4();
+    for (int r = r0 + rl; r < r1; r += RL) {
+        float4 d = sub4(load_u(a, (int64_t)r * a.C + c), mean);
+        acc = add4(acc, mul4(d, d));
+    }
+    const float4 m2 = block_colsum(acc, sh, rl, cq);
+    if (rl == 0) {
+        float* p = a.part + ((int64_t)(s * a.chunks + j) * 2) * a.C + c;
+        st4(p, mean);
+        st4(p + a.C, m2);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void bn_finalize_kernel(BnArgs a) {
+    const int c = blockIdx.x * THREADS + threadIdx.x, s = blockIdx.y;
+    if (c >= a.C) return;
+    const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1];
+    if (seg1 <= seg0) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j = 0; j * CHUNK < seg1 - seg0; ++j) {   // Chan et al. pairwise update, chunk order
+        const float nb = (float)min(CHUNK, seg1 - seg0 - j * CHUNK);
+        const float* p = a.part + ((int64_t)(s * a.chunks + j) * 2) * a.C + c;
+        const float mb = p[0], m2b = p[a.C];
+        const float nt = n + nb, d = mb - mean;
+        mean += d * (nb / nt);
+        m2 += m2b + d * d * (n * nb / nt);
+        n = nt;
+    }
+    a.save_mean[(int64_t)s * a.C + c] = mean;
+    a.save_rstd[(int64_t)s * a.C + c] = rsqrtf(m2 / n + a.cfg.eps);
+}
+
+__global__ __launch_bounds__(THREADS) void bn_apply_long_kernel(BnArgs a) {
+    const int s = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = blockIdx.y * COLS + cq * 4;
+    const int seg1 = a.seg_ptr[s + 1];
+    const int r0 = a.seg_ptr[s] + j * CHUNK, r1 = min(r0 + CHUNK, seg1);
+    if (r0 >= seg1) return;
+    float4 mean, rstd;
+    stats_for(a, s, c, &mean, &rstd);
+    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int64_t off = (int64_t)r * a.C + c;
+        float4 gate;
+        st4(a.y + off, bn_apply(a, load_u(a, off), mean, rstd, gam, bet, off >> 2, &gate));
+    }
+}
+
+// ------------------------------------------------------------------- backward
+// g_aff = g_y * gate(relu, dropout); needs xhat.  returns g_aff and xhat.
+__device__ __forceinline__ void bwd_elem(const BnArgs& a, int64_t off, float4 mean, float4 rstd, float4 gam, float4 bet,
+                                         float4* gaff, float4* xhat) {
+    const float4 u = load_u(a, off);
+    float4 gate;
+    (void)bn_apply(a, u, mean, rstd, gam, bet, off >> 2, &gate);
+    *xhat = mul4(sub4(u, mean), rstd);
+    *gaff = mul4(ld4(a.gy + off), gate);
+}
+
+__device__ __forceinline__ float4 bwd_input(const BnArgs& a, float4 gaff, float4 xhat, float4 s1, float4 s2, float4 gam,
+                                            float4 rstd, float inv_n) {
+    float4 k = mul4(gam, rstd);
+    if (!a.cfg.training) return mul4(k, gaff);   // running statistics are constants
+    return make_float4(k.x * (gaff.x - s1.x * inv_n - xhat.x * s2.x * inv_n), k.y * (gaff.y - s1.y * inv_n - xhat.y * s2.y * inv_n),
+                       k.z * (gaff.z - s1.z * inv_n - xhat.z * s2.z * inv_n), k.w * (gaff.w - s1.w * inv_n - xhat.w * s2.w * inv_n));
+}
+
+__global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
+    __shared__ float4 sh[RL][CQ];
+    const int s = blockIdx.x, cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int c = blockIdx.y * COLS + cq * 4;
+    const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
+    float* ss = a.segsum + (int64_t)s * 2 * a.C + c;
+    if (n <= 0) {
+        if (rl == 0) { st4(ss, zero4()); st4(ss + a.C, zero4()); }
+        return;
+    }
+    float4 mean, rstd;
+    stats_for(a, s, c, &mean, &rstd);
+    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    float4 a1 = zero4(), a2 = zero4();
+    for (int r = r0 + rl; r < r1; r += RL) {
+        float4 g, xh;
+        bwd_elem(a, (int64_t)r * a.C + c, mean, rstd, gam, bet, &g, &xh);
+        a1 = add4(a1, g);
+        a2 = add4(a2, mul4(g, xh));
+    }
+    const float4 s1 = block_colsum(a1, sh, rl, cq);
+    const float4 s2 = block_colsum(a2, sh, rl, cq);
+    if (rl == 0) { st4(ss, s1); st4(ss + a.C, s2); }
+    const float inv_n = 1.f / n;
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int64_t off = (int64_t)r * a.C + c;
+        float4 g, xh;
+        bwd_elem(a, off, mean, rstd, gam, bet, &g, &xh);
+        st4(a.y + off, bwd_input(a, g, xh, s1, s2, gam, rstd, inv_n));
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void bn_bwd_partial_kernel(BnArgs a) {
+    __shared__ float4 sh[RL][CQ];
+    const int s = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = blockIdx.y * COLS + cq * 4;
+    const int seg1 = a.seg_ptr[s + 1];
+    const int r0 = a.seg_ptr[s] + j * CHUNK, r1 = min(r0 + CHUNK, seg1);
+    if (r0 >= seg1) return;
+    float4 mean, rstd;
+    stats_for(a, s, c, &mean, &rstd);
+    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    float4 a1 = zero4(), a2 = zero4();
+    for (int r = r0 + rl; r < r1; r += RL) {
+        float4 g, xh;
+        bwd_elem(a, (int64_t)r * a.C + c, mean, rstd, gam, bet, &g, &xh);
+        a1 = add4(a1, g);
+        a2 = add4(a2, mul4(g, xh));
+    }
+    const float4 s1 = block_colsum(a1, sh, rl, cq);
+    const float4 s2 = block_colsum(a2, sh, rl, cq);
+    if (rl == 0) {
+        float* p = a.part + ((int64_t)(s * a.chunks + j) * 2) * a.C + c;
+        st4(p, s1);
+        st4(p + a.C, s2);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void bn_bwd_finalize_kernel(BnArgs a) {
+    const int c = blockIdx.x * THREADS + threadIdx.x, s = blockIdx.y;
+    if (c >= a.C) return;
+    const int len = a.seg_ptr[s + 1] - a.seg_ptr[s];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j * CHUNK < len; ++j) {
+        const float* p = a.part + ((int64_t)(s * a.chunks + j) * 2) * a.C + c;
+        s1 += p[0];
+        s2 += p[a.C];
+    }
+    a.segsum[(int64_t)s * 2 * a.C + c] = s1;
+    a.segsum[(int64_t)s * 2 * a.C + a.C + c] = s2;
+}
+
+__global__ __launch_bounds__(THREADS) void bn_bwd_apply_long_kernel(BnArgs a) {
+    const int s = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = blockIdx.y * COLS + cq * 4;
+    const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1];
+    const int r0 = seg0 + j * CHUNK, r1 = min(r0 + CHUNK, seg1);
+    if (r0 >= seg1) return;
+    float4 mean, rstd;
+    stats_for(a, s, c, &mean, &rstd);
+    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    const float4 s1 = ld4(a.segsum + (int64_t)s * 2 * a.C + c), s2 = ld4(a.segsum + (int64_t)s * 2 * a.C + a.C + c);
+    const float inv_n = 1.f / (seg1 - seg0);
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int64_t off = (int64_t)r * a.C + c;
+        float4 g, xh;
+        bwd_elem(a, off, mean, rstd, gam, bet, &g, &xh);
+        st4(a.y + off, bwd_input(a, g, xh, s1, s2, gam, rstd, inv_n));
+    }
+}
+
+// g_gamma[grp] = sum over the group's segments of sum(g*xhat); g_beta likewise.  [lo,hi) segments.
+__global__ __launch_bounds__(THREADS) void bn_param_grad_kernel(const float* __restrict__ segsum, int C, int lo, int hi,
+                                                                float* g_gamma, float* g_beta) {
+    const int c = blockIdx.x * THREADS + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = lo; s < hi; ++s) {
+        s1 += segsum[(int64_t)s * 2 * C + c];
+        s2 += segsum[(int64_t)s * 2 * C + C + c];
+    }
+    g_beta[c] = s1;
+    g_gamma[c] = s2;
+}
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+int chunks_for(int64_t max_seg_rows) { return (int)((max_seg_rows + CHUNK - 1) / CHUNK); }
+
+int common_check(const char* who, int64_t rows, int C, int S, int64_t max_seg_rows, const gmp_bn_config* cfg) {
+    if (!cfg) return gmp::fail(GMP_ERR_ARG, "%s: null config", who);
+    if (rows < 0 || S < 0 || C <= 0 || C % COLS != 0)
+        return gmp::fail(GMP_ERR_ARG, "%s: rows=%lld S=%d C=%d (C must be a multiple of %d)", who, (long long)rows, S, C, COLS);
+    if (rows > INT32_MAX) return gmp::fail(GMP_ERR_ARG, "%s: rows beyond int32", who);
+    if (max_seg_rows < 0 || max_seg_rows > rows) return gmp::fail(GMP_ERR_ARG, "%s: max_seg_rows %lld", who, (long long)max_seg_rows);
+    if (cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f) return gmp::fail(GMP_ERR_ARG, "%s: dropout_p %f", who, cfg->dropout_p);
+    return GMP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max_seg_rows) {
+    (void)rows;
+    size_t b = al((size_t)S * 2 * C * sizeof(float));
+    if (max_seg_rows > SHORT_MAX) b += al((size_t)S * chunks_for(max_seg_rows) * 2 * C * sizeof(float));
+    return b + 256;
+}
+
+extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, int S, int64_t max_seg_rows,
+                          int64_t rows, int C, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float* save_mean, float* save_rstd, float* y, const gmp_bn_config* cfg,
+                          void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    if (int rc = common_check("bn_fwd", rows, C, S, max_seg_rows, cfg)) return rc;
+    if (rows == 0 || S == 0) return GMP_OK;
+    if (!x || !seg_ptr || !gamma || !beta || !y) return gmp::fail(GMP_ERR_ARG, "bn_fwd: null pointer");
+    if (cfg->training && (!save_mean || !save_rstd)) return gmp::fail(GMP_ERR_ARG, "bn_fwd: training needs save_mean/save_rstd");
+    if (!cfg->training && (!running_mean || !running_var)) return gmp::fail(GMP_ERR_ARG, "bn_fwd: eval needs running stats");
+    if (ws_bytes < gmp_bn_workspace_bytes(rows, C, S, max_seg_rows) || !ws) return gmp::fail(GMP_ERR_WORKSPACE, "bn_fwd: workspace");
+    hipStream_t st = (hipStream_t)stream;
+    BnArgs a{};
+    a.x = x; a.res = residual; a.seg_ptr = seg_ptr; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
+    a.running_mean = running_mean; a.running_var = running_var; a.save_mean = save_mean; a.save_rstd = save_rstd;
+    a.y = y; a.cfg = *cfg;
+    a.part = (float*)((char*)ws + al((size_t)S * 2 * C * sizeof(float)));
+    a.chunks = chunks_for(max_seg_rows);
+    const dim3 blk(THREADS);
+    if (max_seg_rows <= SHORT_MAX) {
+        hipLaunchKernelGGL(bn_fwd_short_kernel, dim3(S, C / COLS), blk, 0, st, a);
+    } else {
+        const dim3 grid(S * a.chunks, C / COLS);
+        if (cfg->training) {
+            hipLaunchKernelGGL(bn_partial_kernel, grid, blk, 0, st, a);
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + THREADS - 1) / THREADS, S), blk, 0, st, a);
+        }
+        hipLaunchKernelGGL(bn_apply_long_kernel, grid, blk, 0, st, a);
+    }
+    if (cfg->training && running_mean && running_var)
+        hipLaunchKernelGGL(bn_running_kernel, dim3((C + THREADS - 1) / THREADS), blk, 0, st, a);
+    return gmp::check_launch("bn_fwd kernels");
+}
+
+extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr, int S,
+                          int64_t max_seg_rows, int64_t rows, int C, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, const float* save_mean,
+                          const float* save_rstd, float* g_u, float* g_gamma, float* g_beta,
+                          const int32_t* grp_seg_ptr_host, int G, const gmp_bn_config* cfg, void* ws, size_t ws_bytes,
+                          gmp_stream_t stream) {
+    if (int rc = common_check("bn_bwd", rows, C, S, max_seg_rows, cfg)) return rc;
+    if (G < 0 || (G > 0 && (!grp_seg_ptr_host || !g_gamma || !g_beta))) return gmp::fail(GMP_ERR_ARG, "bn_bwd: group arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0 || S == 0) {
+        if (G > 0) {
+            (void)hipMemsetAsync(g_gamma, 0, (size_t)G * C * sizeof(float), st);
+            (void)hipMemsetAsync(g_beta, 0, (size_t)G * C * sizeof(float), st);
+        }
+        return GMP_OK;
+    }
+    if (!g_y || !x || !seg_ptr || !gamma || !beta || !g_u) return gmp::fail(GMP_ERR_ARG, "bn_bwd: null pointer");
+    if (cfg->training && (!save_mean || !save_rstd)) return gmp::fail(GMP_ERR_ARG, "bn_bwd: training needs saved stats");
+    if (!cfg->training && (!running_mean || !running_var)) return gmp::fail(GMP_ERR_ARG, "bn_bwd: eval needs running stats");
+    if (ws_bytes < gmp_bn_workspace_bytes(rows, C, S, max_seg_rows) || !ws) return gmp::fail(GMP_ERR_WORKSPACE, "bn_bwd: workspace");
+    for (int g = 0; g < G; ++g)
+        if (grp_seg_ptr_host[g] < 0 || grp_seg_ptr_host[g] > grp_seg_ptr_host[g + 1] || grp_seg_ptr_host[g + 1] > S)
+            return gmp::fail(GMP_ERR_ARG, "bn_bwd: group %d covers segments [%d,%d) of %d", g, grp_seg_ptr_host[g], grp_seg_ptr_host[g + 1], S);
+    BnArgs a{};
+    a.x = x; a.res = residual; a.gy = g_y; a.seg_ptr = seg_ptr; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
+    a.running_mean = (float*)running_mean; a.running_var = (float*)running_var;
+    a.save_mean = (float*)save_mean; a.save_rstd = (float*)save_rstd; a.y = g_u; a.cfg = *cfg;
+    a.segsum = (float*)ws;
+    a.part = (float*)((char*)ws + al((size_t)S * 2 * C * sizeof(float)));
+    a.chunks = chunks_for(max_seg_rows);
+    const dim3 blk(THREADS);
+    if (max_seg_rows <= SHORT_MAX) {
+        hipLaunchKernelGGL(bn_bwd_short_kernel, dim3(S, C / COLS), blk, 0, st, a);
+    } else {
+        const dim3 grid(S * a.chunks, C / COLS);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, blk, 0, st, a);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + THREADS - 1) / THREADS, S), blk, 0, st, a);
+        hipLaunchKernelGGL(bn_bwd_apply_long_kernel, grid, blk, 0, st, a);
+    }
+    for (int g = 0; g < G; ++g)
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + THREADS - 1) / THREADS), blk, 0, st, (const float*)a.segsum, C,
+                           grp_seg_ptr_host[g], grp_seg_ptr_host[g + 1], g_gamma + (size_t)g * C, g_beta + (size_t)g * C);
+    return gmp::check_launch("bn_bwd kernels");
+}

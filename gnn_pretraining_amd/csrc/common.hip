@@ -1,0 +1,19 @@
+// libgnnmp: version + error plumbing.
+#include <stdarg.h>
+
+#include "gnnmp_internal.h"
+
+namespace gmp {
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace gmp
+
+extern "C" int gmp_version(void) { return 100; }
+extern "C" const char* gmp_last_error_string(void) { return gmp::err_buf(); }

@@ -1,0 +1,281 @@
+// COO (int64) -> CSR (int32) in both orientations, deterministic (stable by edge id).
+//
+// Small graphs (the pre-training batches: N <= 16384 rows) are built by ONE
+// workgroup per orientation entirely in LDS: histogram, scan, fill, per-row
+// ordering -- one launch instead of seven.  Larger graphs (Cora upward, the
+// roofline ladder) use the multi-kernel path.  Both give identical arrays.
+#include <algorithm>
+
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int SMALL_MAX_N = 16384;   // 2 * 4 B * N <= 128 KiB of the 160 KiB LDS
+constexpr int SMALL_THREADS = 1024;
+constexpr int THREAD_SORT_MAX_DEG = 32;
+
+// rank-sort one row: out[start + rank(v)] = v  (edge ids within a row are distinct)
+__device__ __forceinline__ void sort_row_serial(const int* __restrict__ tmp, int start, int deg,
+                                                const int64_t* __restrict__ other, int* __restrict__ perm,
+                                                int* __restrict__ col) {
+    for (int i = 0; i < deg; ++i) {
+        int v = tmp[start + i];
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) rank += (tmp[start + j] < v);
+        perm[start + rank] = v;
+        col[start + rank] = (int)other[v];
+    }
+}
+
+__device__ __forceinline__ void sort_row_wave(const int* __restrict__ tmp, int start, int deg, int lane,
+                                              const int64_t* __restrict__ other, int* __restrict__ perm,
+                                              int* __restrict__ col) {
+    for (int i = lane; i < deg; i += GMP_WAVE) {
+        int v = tmp[start + i];
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) rank += (tmp[start + j] < v);
+        perm[start + rank] = v;
+        col[start + rank] = (int)other[v];
+    }
+}
+
+// ------------------------------------------------------------------ small path
+__global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(
+    const int64_t* __restrict__ ei, int N, int E, int* rowptr0, int* col0, int* perm0, int* rowptr1, int* col1,
+    int* perm1, int* status, int* tmp_all) {
+    extern __shared__ int lds[];
+    __shared__ int part[SMALL_THREADS];
+    const int o = blockIdx.x;  // 0: group by target (row 1 of edge_index), 1: group by source
+    const int64_t* key = o == 0 ? ei + E : ei;
+    const int64_t* other = o == 0 ? ei : ei + E;
+    int* rowptr = o == 0 ? rowptr0 : rowptr1;
+    int* col = o == 0 ? col0 : col1;
+    int* perm = o == 0 ? perm0 : perm1;
+    int* tmp = tmp_all + (size_t)o * E;
+    int* cnt = lds;            // [N+1]
+    int* cur = lds + (N + 1);  // [N]
+    const int t = threadIdx.x;
+
+    for (int i = t; i <= N; i += SMALL_THREADS) cnt[i] = 0;
+    for (int i = t; i < N; i += SMALL_THREADS) cur[i] = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int e = t; e < E; e += SMALL_THREADS) {
+        int64_t k = key[e], v = other[e];
+        if (k >= 0 && k < N && v >= 0 && v < N) atomicAdd(&cnt[(int)k], 1);
+        else ++bad;
+    }
+    if (o == 0 && bad) atomicAdd(status, bad);
+    __syncthreads();
+    // exclusive scan of cnt[0..N]: contiguous chunk per thread, then scan of chunk sums
+    const int chunk = (N + 1 + SMALL_THREADS - 1) / SMALL_THREADS;
+    const int lo = min(t * chunk, N + 1), hi = min(lo + chunk, N + 1);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < SMALL_THREADS; d <<= 1) {  // Hillis-Steele inclusive scan
+        int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t == 0 ? 0 : part[t - 1];
+    for (int i = lo; i < hi; ++i) {
+        int c = cnt[i];
+        cnt[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int i = t; i <= N; i += SMALL_THREADS) rowptr[i] = cnt[i];
+    for (int e = t; e < E; e += SMALL_THREADS) {
+        int64_t k = key[e], v = other[e];
+        if (k >= 0 && k < N && v >= 0 && v < N) tmp[cnt[(int)k] + atomicAdd(&cur[(int)k], 1)] = e;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int r = t; r < N; r += SMALL_THREADS) {
+        int start = cnt[r], deg = cnt[r + 1] - start;
+        if (deg <= THREAD_SORT_MAX_DEG) sort_row_serial(tmp, start, deg, other, perm, col);
+    }
+    const int wave = t / GMP_WAVE, lane = t % GMP_WAVE;
+    for (int r = wave; r < N; r += SMALL_THREADS / GMP_WAVE) {
+        int start = cnt[r], deg = cnt[r + 1] - start;
+        if (deg > THREAD_SORT_MAX_DEG) sort_row_wave(tmp, start, deg, lane, other, perm, col);
+    }
+}
+
+// ------------------------------------------------------------------ large path
+__global__ void hist_kernel(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int N, int64_t E,
+                            int* cnt, int* status) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (; e < E; e += stride) {
+        int64_t k = key[e], v = other[e];
+        if (k >= 0 && k < N && v >= 0 && v < N) atomicAdd(&cnt[k], 1);
+        else ++bad;
+    }
+    if (status && bad) atomicAdd(status, bad);
+}
+
+constexpr int SCAN_T = 256, SCAN_PER = 8, SCAN_BLOCK = SCAN_T * SCAN_PER;
+
+// in-place exclusive scan of each 2048-element block; block totals -> sums
+__global__ __launch_bounds__(SCAN_T) void scan_blocks_kernel(int* data, int64_t n, int* sums) {
+    __shared__ int part[SCAN_T];
+    int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_PER;
+    int v[SCAN_PER], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) {
+        v[i] = base + i < n ? data[base + i] : 0;
+        s += v[i];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        int x = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += x;
+        __syncthreads();
+    }
+    int run = threadIdx.x == 0 ? 0 : part[threadIdx.x - 1];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == SCAN_T - 1) sums[blockIdx.x] = part[SCAN_T - 1];
+}
+
+// exclusive scan of the block totals by one workgroup (sequential over chunks)
+__global__ __launch_bounds__(SCAN_T) void scan_sums_kernel(int* sums, int nb) {
+    __shared__ int part[SCAN_T];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += SCAN_T) {
+        int i = base + threadIdx.x;
+        int v = i < nb ? sums[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < SCAN_T; d <<= 1) {
+            int x = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += x;
+            __syncthreads();
+        }
+        int c = carry;
+        if (i < nb) sums[i] = c + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + part[SCAN_T - 1];
+        __syncthreads();
+    }
+}
+
+__global__ void scan_add_kernel(int* data, int64_t n, const int* sums) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += sums[i / SCAN_BLOCK];
+}
+
+__global__ void fill_kernel(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int N, int64_t E,
+                            const int* __restrict__ rowptr, int* cur, int* tmp) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < E; e += stride) {
+        int64_t k = key[e], v = other[e];
+        if (k >= 0 && k < N && v >= 0 && v < N) tmp[rowptr[k] + atomicAdd(&cur[k], 1)] = (int)e;
+    }
+}
+
+__global__ void sort_rows_thread_kernel(const int* __restrict__ rowptr, const int* __restrict__ tmp,
+                                        const int64_t* __restrict__ other, int N, int* perm, int* col) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    int start = rowptr[r], deg = rowptr[r + 1] - start;
+    if (deg <= THREAD_SORT_MAX_DEG) sort_row_serial(tmp, start, deg, other, perm, col);
+}
+
+__global__ void sort_rows_wave_kernel(const int* __restrict__ rowptr, const int* __restrict__ tmp,
+                                      const int64_t* __restrict__ other, int N, int* perm, int* col) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) / GMP_WAVE, lane = threadIdx.x % GMP_WAVE;
+    int nw = gridDim.x * blockDim.x / GMP_WAVE;
+    for (int r = wave; r < N; r += nw) {
+        int start = rowptr[r], deg = rowptr[r + 1] - start;
+        if (deg > THREAD_SORT_MAX_DEG) sort_row_wave(tmp, start, deg, lane, other, perm, col);
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t gmp_csr_build_workspace_bytes(int64_t N, int64_t E) {
+    if (N < 0 || E < 0) return 0;
+    // tmp perm for two orientations + cursor + scan block sums
+    return align256(2 * (size_t)E * 4) + align256((size_t)N * 4 + 4) +
+           align256(((size_t)(N + 1) / SCAN_BLOCK + 2) * 4) + 256;
+}
+
+extern "C" int gmp_csr_build(const int64_t* ei, int64_t N, int64_t E, int32_t* rowptr, int32_t* col, int32_t* perm,
+                             int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t, int32_t* status, void* ws,
+                             size_t ws_bytes, gmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || E < 0 || N > INT32_MAX - 1 || E > INT32_MAX)
+        return gmp::fail(GMP_ERR_ARG, "csr_build: N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
+    if (!rowptr || !status || (E > 0 && (!ei || !col || !perm)))
+        return gmp::fail(GMP_ERR_ARG, "csr_build: null pointer");
+    const bool both = rowptr_t != nullptr;
+    if (both && E > 0 && (!col_t || !perm_t)) return gmp::fail(GMP_ERR_ARG, "csr_build: partial transposed outputs");
+    if (ws_bytes < gmp_csr_build_workspace_bytes(N, E))
+        return gmp::fail(GMP_ERR_WORKSPACE, "csr_build: workspace %zu < %zu", ws_bytes,
+                         gmp_csr_build_workspace_bytes(N, E));
+    hipError_t herr = hipMemsetAsync(status, 0, sizeof(int), stream);
+    if (herr != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "csr_build: memset: %s", hipGetErrorString(herr));
+    char* w = (char*)ws;
+    int* tmp = (int*)w;
+    w += align256(2 * (size_t)E * 4);
+    int* cur = (int*)w;
+    w += align256((size_t)N * 4 + 4);
+    int* sums = (int*)w;
+
+    if (N <= SMALL_MAX_N) {
+        size_t lds = (size_t)(2 * N + 1) * sizeof(int);
+        static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)csr_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (2 * SMALL_MAX_N + 1) * (int)sizeof(int));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(csr_small_kernel, dim3(both ? 2 : 1), dim3(SMALL_THREADS), lds, stream, ei, (int)N, (int)E,
+                           rowptr, col, perm, rowptr_t, col_t, perm_t, status, tmp);
+        return gmp::check_launch("csr_small_kernel");
+    }
+    for (int o = 0; o < (both ? 2 : 1); ++o) {
+        const int64_t* key = o == 0 ? ei + E : ei;
+        const int64_t* other = o == 0 ? ei : ei + E;
+        int* rp = o == 0 ? rowptr : rowptr_t;
+        int* cl = o == 0 ? col : col_t;
+        int* pm = o == 0 ? perm : perm_t;
+        int* tp = tmp + (size_t)o * E;
+        hipMemsetAsync(rp, 0, (size_t)(N + 1) * 4, stream);
+        hipMemsetAsync(cur, 0, (size_t)N * 4, stream);
+        int gb = (int)std::min<int64_t>(gmp::cdiv(E, 256), 4096);
+        if (E > 0) hipLaunchKernelGGL(hist_kernel, dim3(gb), dim3(256), 0, stream, key, other, (int)N, E, rp,
+                                      o == 0 ? status : (int*)nullptr);
+        int nb = gmp::cdiv(N + 1, SCAN_BLOCK);
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(SCAN_T), 0, stream, rp, N + 1, sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_T), 0, stream, sums, nb);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(gmp::cdiv(N + 1, 256)), dim3(256), 0, stream, rp, N + 1, sums);
+        if (E > 0) {
+            hipLaunchKernelGGL(fill_kernel, dim3(gb), dim3(256), 0, stream, key, other, (int)N, E, rp, cur, tp);
+            hipLaunchKernelGGL(sort_rows_thread_kernel, dim3(gmp::cdiv(N, 256)), dim3(256), 0, stream, rp, tp, other,
+                               (int)N, pm, cl);
+            int wb = (int)std::min<int64_t>(gmp::cdiv(N, 4), 2048);
+            hipLaunchKernelGGL(sort_rows_wave_kernel, dim3(wb), dim3(256), 0, stream, rp, tp, other, (int)N, pm, cl);
+        }
+        int rc = gmp::check_launch("csr_build large path");
+        if (rc) return rc;
+    }
+    return GMP_OK;
+}

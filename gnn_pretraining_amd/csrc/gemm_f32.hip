@@ -1,0 +1,310 @@
+// fp32 GEMM on the CDNA4 f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32
+// products and accumulation (gfx950 has no TF32/xf32), at the fp32 vector peak.
+// The dense post-aggregation feature transform of GINConv and every head Linear.
+//
+// Block = 4 waves in a 2x2 arrangement over a BMxBN tile (128x128 or 64x64); each
+// wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles, accumulators stay in registers for
+// the whole K loop.  Operands are staged through LDS in k-major order ([k][i]) so a
+// wave's A/B fragment read (lane -> A[i = lane&31][k = lane>>5]) is 32 consecutive
+// floats per half-wave: conflict-free ds_read_b32.  Global tiles are prefetched into
+// registers one K-step ahead of the MFMAs.
+#include <algorithm>
+
+#include "gnnmp_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int THREADS = 256;
+
+// Load one BK x R operand tile into registers.
+//  KMAJOR=false: memory is [R_total rows][K] (k contiguous, leading dim ld)  -> row-major activations / Linear weights
+//  KMAJOR=true : memory is [K][R_total]      (row index contiguous)          -> already k-major
+template <int R, bool KMAJOR>
+struct TileLoader {
+    static constexpr int NV = R * BK / 4 / THREADS;   // float4 per thread
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rtot, int64_t k0,
+                                         int64_t K, bool vec, int t) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int f = t + s * THREADS;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!KMAJOR) {
+                const int row = f / (BK / 4), kq = f % (BK / 4);
+                const int64_t gr = r0 + row, gk = k0 + 4 * kq;
+                if (gr < rtot) {
+                    const float* p = P + gr * ld + gk;
+                    if (vec && gk + 3 < K) x = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gk < K) x.x = p[0];
+                        if (gk + 1 < K) x.y = p[1];
+                        if (gk + 2 < K) x.z = p[2];
+                        if (gk + 3 < K) x.w = p[3];
+                    }
+                }
+            } else {
+                const int k = f / (R / 4), q = f % (R / 4);
+                const int64_t gk = k0 + k, gr = r0 + 4 * q;
+                if (gk < K) {
+                    const float* p = P + gk * ld + gr;
+                    if (vec && gr + 3 < rtot) x = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gr < rtot) x.x = p[0];
+                        if (gr + 1 < rtot) x.y = p[1];
+                        if (gr + 2 < rtot) x.z = p[2];
+                        if (gr + 3 < rtot) x.w = p[3];
+                    }
+                }
+            }
+            v[s] = x;
+        }
+    }
+
+    static constexpr int LD = KMAJOR ? R + 4 : R + 1;   // +4 keeps b128 stores aligned; +1 spreads the transposing b32 stores
+
+    __device__ __forceinline__ void store(float* __restrict__ S, int t) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int f = t + s * THREADS;
+            if (!KMAJOR) {
+                const int row = f / (BK / 4), kq = f % (BK / 4);
+                S[(4 * kq + 0) * LD + row] = v[s].x;
+                S[(4 * kq + 1) * LD + row] = v[s].y;
+                S[(4 * kq + 2) * LD + row] = v[s].z;
+                S[(4 * kq + 3) * LD + row] = v[s].w;
+            } else {
+                const int k = f / (R / 4), q = f % (R / 4);
+                *reinterpret_cast<float4*>(&S[k * LD + 4 * q]) = v[s];
+            }
+        }
+    }
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    const float* bias;
+    float* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha;
+    int accumulate, relu;
+    int splitk;           // >1: blockIdx.z = k-slice, partial tiles go to `partial` [splitk][M][N]
+    float* partial;
+    int vecA, vecB;
+};
+
+template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
+    using LA = TileLoader<BM, A_KMAJOR>;
+    using LB = TileLoader<BN, B_KMAJOR>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) float As[BK * LA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LB::LD];
+
+    const int t = threadIdx.x, lane = t % 64, wv = t / 64;
+    const int wm = wv / 2, wn = wv % 2, l31 = lane & 31, half = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    // k range of this block (split-K slices are multiples of BK)
+    int64_t kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        const int64_t steps = (g.K + BK - 1) / BK;
+        const int64_t per = (steps + g.splitk - 1) / g.splitk;
+        kbeg = (int64_t)blockIdx.z * per * BK;
+        kend = kbeg + per * BK < g.K ? kbeg + per * BK : g.K;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LA la;
+    LB lb;
+    if (kbeg < kend) {
+        la.load(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, t);
+        lb.load(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, t);
+    }
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        la.store(As, t);
+        lb.store(Bs, t);
+        __syncthreads();
+        if (k0 + BK < kend) {   // prefetch the next K-step while this one is multiplied
+            la.load(g.A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, t);
+            lb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + half) * LA::LD + wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + half) * LB::LD + wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* out = g.C;
+    int64_t ldo = g.ldc;
+    const bool partial = g.splitk > 1;
+    if (partial) {
+        out = g.partial + (int64_t)blockIdx.z * g.M * g.N;
+        ldo = g.N;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + wn * (BN / 2) + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (!partial) {
+                    v = g.alpha * v + bv;
+                    if (g.accumulate) v += out[row * ldo + col];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                }
+                out[row * ldo + col] = v;
+            }
+        }
+}
+
+// sum the split-K slices in slice order (deterministic) and apply the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+    const int64_t total = g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < g.splitk; ++z) s += g.partial[(int64_t)z * total + i];
+        const int64_t row = i / g.N, col = i % g.N;
+        float v = g.alpha * s + (g.bias ? g.bias[col] : 0.f);
+        if (g.accumulate) v += g.C[row * g.ldc + col];
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.C[row * g.ldc + col] = v;
+    }
+}
+
+// ---- column sums (bias gradients), deterministic two-stage ---------------------
+constexpr int CS_ROWS = 256;   // rows per partial block
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, float* __restrict__ part,
+                                                             int64_t M, int64_t N, int64_t lda) {
+    // block = 64 columns x 4 row lanes
+    __shared__ float sh[4][64];
+    const int c = threadIdx.x % 64, rl = threadIdx.x / 64;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+    float s = 0.f;
+    if (col < N)
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += A[r * lda + col];
+    sh[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           int64_t nparts, int64_t N, int accumulate) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int64_t p = 0; p < nparts; ++p) s += part[p * N + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+template <int BM, int BN>
+void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st) {
+    switch (mode) {
+        case GMP_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(THREADS), 0, st, g); break;
+        case GMP_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(THREADS), 0, st, g); break;
+        default:          hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(THREADS), 0, st, g); break;
+    }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+    (void)mode;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // split-K is used only when the output alone cannot fill the chip and K is long
+    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 256 || K < 8 * BK) return 0;
+    int64_t sk = (512 + tiles - 1) / tiles;
+    const int64_t steps = (K + BK - 1) / BK;
+    if (sk > steps / 2) sk = steps / 2;
+    if (sk < 2) return 0;
+    return (size_t)sk * M * N * sizeof(float);
+}
+
+extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const float* bias, float* C, int64_t M, int64_t N,
+                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int accumulate, int relu,
+                            void* workspace, size_t workspace_bytes, gmp_stream_t stream) {
+    if (mode < 0 || mode > 2) return gmp::fail(GMP_ERR_ARG, "gemm: mode %d", mode);
+    if (M < 0 || N < 0 || K < 0) return gmp::fail(GMP_ERR_ARG, "gemm: negative size");
+    if (M == 0 || N == 0) return GMP_OK;
+    if (!C || (K > 0 && (!A || !B))) return gmp::fail(GMP_ERR_ARG, "gemm: null pointer");
+    const int64_t need_lda = mode == GMP_GEMM_TN ? M : K, need_ldb = mode == GMP_GEMM_NT ? K : N;
+    if (lda < need_lda || ldb < need_ldb || ldc < N)
+        return gmp::fail(GMP_ERR_ARG, "gemm: leading dims (%lld,%lld,%lld) too small for M=%lld N=%lld K=%lld mode %d",
+                         (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, mode);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{A, B, bias, C, M, N, K, lda, ldb, ldc, alpha, accumulate, relu, 1, nullptr,
+               (lda % 4 == 0) && aligned16(A), (ldb % 4 == 0) && aligned16(B)};
+    const size_t want = gmp_gemm_f32_workspace_bytes(mode, M, N, K);
+    if (want && workspace && workspace_bytes >= want) {
+        g.splitk = (int)(want / ((size_t)M * N * sizeof(float)));
+        g.partial = (float*)workspace;
+    }
+    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (g.splitk == 1 && big_tiles >= 256) {
+        launch_mode<128, 128>(mode, g, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), 1), st);
+    } else {
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st);
+    }
+    if (int rc = gmp::check_launch("gemm_kernel")) return rc;
+    if (g.splitk > 1) {
+        int blocks = (int)std::min<int64_t>((M * N + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+        return gmp::check_launch("splitk_reduce_kernel");
+    }
+    return GMP_OK;
+}
+
+extern "C" size_t gmp_colsum_workspace_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * sizeof(float);
+}
+
+extern "C" int gmp_colsum(const float* A, float* out, int64_t M, int64_t N, int64_t lda, int accumulate, void* ws,
+                          size_t ws_bytes, gmp_stream_t stream) {
+    if (M < 0 || N < 0 || lda < N) return gmp::fail(GMP_ERR_ARG, "colsum: bad size");
+    if (N == 0) return GMP_OK;
+    if (!out || (M > 0 && !A)) return gmp::fail(GMP_ERR_ARG, "colsum: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        if (!accumulate) (void)hipMemsetAsync(out, 0, N * sizeof(float), st);
+        return GMP_OK;
+    }
+    if (ws_bytes < gmp_colsum_workspace_bytes(M, N) || !ws) return gmp::fail(GMP_ERR_WORKSPACE, "colsum: workspace");
+    const int64_t parts = (M + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)parts), dim3(256), 0, st, A,
+                       (float*)ws, M, N, lda);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const float*)ws, out,
+                       parts, N, accumulate);
+    return gmp::check_launch("colsum kernels");
+}

@@ -1,0 +1,62 @@
+// Internal helpers shared by the libgnnmp kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gnnmp.h"
+
+#define GMP_WAVE 64
+
+namespace gmp {
+
+// thread-local last-error text, read through gmp_last_error_string()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GMP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return GMP_OK;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- Philox4x32-10 (counter-based RNG for dropout; mask is regenerated in the
+// backward pass from (seed, stream, element) instead of being stored) ----------
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+
+// keep-mask for 4 consecutive elements starting at element index 4*q of dropout
+// stream `stream`; returns the multiplier (0 or 1/(1-p)) per element.
+__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint32_t stream, uint64_t q, float p, float inv_keep) {
+    uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), stream, 0x6d70u),
+                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    // u = r * 2^-32 in [0,1); keep iff u >= p
+    const float s = 2.3283064365386963e-10f;
+    float4 o;
+    o.x = ((float)r.x * s >= p) ? inv_keep : 0.f;
+    o.y = ((float)r.y * s >= p) ? inv_keep : 0.f;
+    o.z = ((float)r.z * s >= p) ? inv_keep : 0.f;
+    o.w = ((float)r.w * s >= p) ? inv_keep : 0.f;
+    return o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace gmp

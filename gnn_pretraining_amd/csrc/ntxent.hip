@@ -1,0 +1,163 @@
+// NT-Xent / InfoNCE (SimCLR) loss: normalise -> similarity GEMM (f32 MFMA) ->
+// masked row softmax cross-entropy, and its backward.  The 2n x 2n similarity
+// matrix lives only in the caller's workspace (it is overwritten in place by
+// softmax - onehot, which is all the backward needs).
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct Ws {
+    float* zn;     // [2n,d] normalised rows
+    float* norm;   // [2n]   max(||z||, 1e-12)
+    float* G;      // [2n,2n] sim, then softmax - onehot
+    float* gzn;    // [2n,d]
+    float* rowloss;// [2n]
+};
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Ws carve(void* ws, int64_t n, int d) {
+    char* p = (char*)ws;
+    Ws w;
+    const int64_t R = 2 * n;
+    w.zn = (float*)p; p += al((size_t)R * d * 4);
+    w.norm = (float*)p; p += al((size_t)R * 4);
+    w.G = (float*)p; p += al((size_t)R * R * 4);
+    w.gzn = (float*)p; p += al((size_t)R * d * 4);
+    w.rowloss = (float*)p;
+    return w;
+}
+
+// one wave per row: zn = z / max(||z||, eps)   (F.normalize, eps = 1e-12)
+__global__ __launch_bounds__(THREADS) void normalize_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                            int64_t n, int d, float* __restrict__ zn, float* __restrict__ norm) {
+    const int lane = threadIdx.x % 64;
+    const int64_t row = ((int64_t)blockIdx.x * THREADS + threadIdx.x) / 64;
+    if (row >= 2 * n) return;
+    const float* src = row < n ? z1 + row * d : z2 + (row - n) * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += src[c] * src[c];
+    s = gmp::wave_sum(s);
+    const float nr = fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < d; c += 64) zn[row * d + c] = src[c] / nr;
+    if (lane == 0) norm[row] = nr;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+    const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float t = __shfl_xor(v, o, 64);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < THREADS / 64; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+    return r;
+}
+
+// one block per row i: loss_i = logsumexp_{j != i} sim[i,j] - sim[i,pos];  G[i,:] = softmax - onehot(pos)
+__global__ __launch_bounds__(THREADS) void row_loss_kernel(float* __restrict__ G, int64_t n, float* __restrict__ rowloss) {
+    __shared__ float sh[THREADS / 64];
+    const int64_t R = 2 * n, i = blockIdx.x;
+    float* row = G + i * R;
+    const int64_t pos = i < n ? i + n : i - n;
+    float m = -INFINITY;
+    for (int64_t j = threadIdx.x; j < R; j += THREADS)
+        if (j != i) m = fmaxf(m, row[j]);
+    m = block_reduce(m, sh, true);
+    float s = 0.f;
+    for (int64_t j = threadIdx.x; j < R; j += THREADS)
+        if (j != i) s += expf(row[j] - m);
+    s = block_reduce(s, sh, false);
+    const float lse = m + logf(s);
+    const float sp = row[pos];
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < R; j += THREADS) {
+        float p = j == i ? 0.f : expf(row[j] - lse);
+        if (j == pos) p -= 1.f;
+        row[j] = p;
+    }
+    if (threadIdx.x == 0) rowloss[i] = lse - sp;
+}
+
+__global__ __launch_bounds__(THREADS) void sum_rows_kernel(const float* __restrict__ v, int64_t n, float* out) {
+    __shared__ float sh[THREADS];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += THREADS) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = THREADS / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// g_z = g_scale * (g_zn - zn <zn, g_zn>) / norm     (backward of x / max(||x||, eps) for ||x|| > eps;
+// for ||x|| <= eps the denominator is the constant eps and the projection term vanishes)
+__global__ __launch_bounds__(THREADS) void normalize_bwd_kernel(const float* __restrict__ zn, const float* __restrict__ norm,
+                                                                const float* __restrict__ gzn, const float* __restrict__ g_scale,
+                                                                int64_t n, int d, float* __restrict__ g1, float* __restrict__ g2) {
+    const int lane = threadIdx.x % 64;
+    const int64_t row = ((int64_t)blockIdx.x * THREADS + threadIdx.x) / 64;
+    if (row >= 2 * n) return;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) dot += zn[row * d + c] * gzn[row * d + c];
+    dot = gmp::wave_sum(dot);
+    const float nr = norm[row], gs = g_scale[0];
+    if (nr <= 1e-12f) dot = 0.f;
+    float* dst = row < n ? g1 + row * d : g2 + (row - n) * d;
+    for (int c = lane; c < d; c += 64) dst[c] = gs * (gzn[row * d + c] - zn[row * d + c] * dot) / nr;
+}
+
+int args_ok(const char* who, int64_t n, int d, float T) {
+    if (n < 1 || n > 8192) return gmp::fail(GMP_ERR_ARG, "%s: n=%lld must be in [1,8192]", who, (long long)n);
+    if (d < 1 || d % 4) return gmp::fail(GMP_ERR_ARG, "%s: dim %d must be a positive multiple of 4", who, d);
+    if (!(T > 0.f)) return gmp::fail(GMP_ERR_ARG, "%s: temperature %f", who, T);
+    return GMP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gmp_nt_xent_workspace_bytes(int64_t n, int d) {
+    if (n < 1 || d < 1) return 0;
+    const size_t R = 2 * (size_t)n;
+    return 2 * al(R * d * 4) + 2 * al(R * 4) + al(R * R * 4) + 256;
+}
+
+extern "C" int gmp_nt_xent_fwd(const float* z1, const float* z2, int64_t n, int d, float T, float* loss_sum, void* ws,
+                               size_t ws_bytes, gmp_stream_t stream) {
+    if (int rc = args_ok("nt_xent_fwd", n, d, T)) return rc;
+    if (!z1 || !z2 || !loss_sum || !ws) return gmp::fail(GMP_ERR_ARG, "nt_xent_fwd: null pointer");
+    if (ws_bytes < gmp_nt_xent_workspace_bytes(n, d)) return gmp::fail(GMP_ERR_WORKSPACE, "nt_xent_fwd: workspace");
+    hipStream_t st = (hipStream_t)stream;
+    Ws w = carve(ws, n, d);
+    const int64_t R = 2 * n;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((R * 64 + THREADS - 1) / THREADS)), dim3(THREADS), 0, st, z1, z2, n, d, w.zn, w.norm);
+    if (int rc = gmp_gemm_f32(GMP_GEMM_NT, w.zn, w.zn, nullptr, w.G, R, R, d, d, d, R, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
+    hipLaunchKernelGGL(row_loss_kernel, dim3((unsigned)R), dim3(THREADS), 0, st, w.G, n, w.rowloss);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(THREADS), 0, st, (const float*)w.rowloss, R, loss_sum);
+    return gmp::check_launch("nt_xent_fwd kernels");
+}
+
+extern "C" int gmp_nt_xent_bwd(const float* z1, const float* z2, int64_t n, int d, float T, const float* g_scale,
+                               float* g_z1, float* g_z2, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    (void)z1; (void)z2;
+    if (int rc = args_ok("nt_xent_bwd", n, d, T)) return rc;
+    if (!g_scale || !g_z1 || !g_z2 || !ws) return gmp::fail(GMP_ERR_ARG, "nt_xent_bwd: null pointer");
+    if (ws_bytes < gmp_nt_xent_workspace_bytes(n, d)) return gmp::fail(GMP_ERR_WORKSPACE, "nt_xent_bwd: workspace");
+    hipStream_t st = (hipStream_t)stream;
+    Ws w = carve(ws, n, d);
+    const int64_t R = 2 * n;
+    // d loss / d zn = (G + G^T) zn / T
+    if (int rc = gmp_gemm_f32(GMP_GEMM_NN, w.G, w.zn, nullptr, w.gzn, R, d, R, R, d, d, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
+    if (int rc = gmp_gemm_f32(GMP_GEMM_TN, w.G, w.zn, nullptr, w.gzn, R, d, R, R, d, d, 1.f / T, 1, 0, nullptr, 0, stream)) return rc;
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)((R * 64 + THREADS - 1) / THREADS)), dim3(THREADS), 0, st,
+                       (const float*)w.zn, (const float*)w.norm, (const float*)w.gzn, g_scale, n, d, g_z1, g_z2);
+    return gmp::check_launch("nt_xent_bwd kernels");
+}

@@ -1,0 +1,176 @@
+// Row gathers, max read-out pooling and the link-prediction edge-feature builder.
+// All are HBM/L2-bound row movers: one wave per output row, float4 per lane, so a
+// 256-wide row is one 1-KiB coalesced wave instruction.
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WPB = BLOCK / GMP_WAVE;
+
+__device__ __forceinline__ int64_t wave_id() { return ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / GMP_WAVE; }
+__device__ __forceinline__ int64_t wave_count() { return (int64_t)gridDim.x * WPB; }
+
+__global__ __launch_bounds__(BLOCK) void row_gather_kernel(const float4* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           const int* __restrict__ seg_ptr, float4* __restrict__ out,
+                                                           int64_t M, int64_t nsrc, int F4) {
+    const int lane = threadIdx.x % GMP_WAVE;
+    for (int64_t m = wave_id(); m < M; m += wave_count()) {
+        const int64_t r = idx[m];
+        const bool ok = r >= 0 && r < nsrc;   // out-of-range index -> zero row, never a fault
+        float s = 1.f;
+        if (seg_ptr && ok) {
+            int c = seg_ptr[r + 1] - seg_ptr[r];
+            s = 1.f / (float)(c > 1 ? c : 1);
+        }
+        for (int c = lane; c < F4; c += GMP_WAVE) {
+            float4 v = ok ? src[r * F4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            out[m * F4 + c] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __restrict__ x, const int* __restrict__ ptr,
+                                                            float4* __restrict__ out, int64_t B, int F4) {
+    const int lane = threadIdx.x % GMP_WAVE;
+    for (int64_t b = wave_id(); b < B; b += wave_count()) {
+        const int s = ptr[b], e = ptr[b + 1];
+        for (int c = lane; c < F4; c += GMP_WAVE) {
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> 0 (PyG new_zeros, include_self=False)
+            if (e > s) {
+                m = x[(int64_t)s * F4 + c];
+                for (int r = s + 1; r < e; ++r) {
+                    float4 v = x[(int64_t)r * F4 + c];
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+            out[b * F4 + c] = m;
+        }
+    }
+}
+
+// torch scatter_reduce('amax') backward: gradient split evenly between tied maxima
+__global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
+                                                            const float4* __restrict__ mx, const int* __restrict__ ptr,
+                                                            float4* __restrict__ gx, int64_t B, int F4) {
+    const int lane = threadIdx.x % GMP_WAVE;
+    for (int64_t b = wave_id(); b < B; b += wave_count()) {
+        const int s = ptr[b], e = ptr[b + 1];
+        for (int c = lane; c < F4; c += GMP_WAVE) {
+            const float4 m = mx[b * F4 + c], gg = g[b * F4 + c];
+            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = s; r < e; ++r) {
+                float4 v = x[(int64_t)r * F4 + c];
+                n.x += v.x == m.x; n.y += v.y == m.y; n.z += v.z == m.z; n.w += v.w == m.w;
+            }
+            const float4 q = make_float4(gg.x / n.x, gg.y / n.y, gg.z / n.z, gg.w / n.w);
+            for (int r = s; r < e; ++r) {
+                float4 v = x[(int64_t)r * F4 + c];
+                gx[(int64_t)r * F4 + c] = make_float4(v.x == m.x ? q.x : 0.f, v.y == m.y ? q.y : 0.f,
+                                                      v.z == m.z ? q.z : 0.f, v.w == m.w ? q.w : 0.f);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void lp_feat_fwd_kernel(const float4* __restrict__ h, const int64_t* __restrict__ edges,
+                                                            float4* __restrict__ feat, int64_t N, int64_t K, int F4) {
+    const int lane = threadIdx.x % GMP_WAVE;
+    for (int64_t k = wave_id(); k < K; k += wave_count()) {
+        const int64_t a = edges[k], b = edges[K + k];
+        const bool ok = a >= 0 && a < N && b >= 0 && b < N;
+        for (int c = lane; c < F4; c += GMP_WAVE) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f), d = s;
+            if (ok) { s = h[a * F4 + c]; d = h[b * F4 + c]; }
+            float4* o = feat + k * 3 * F4;
+            o[c] = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
+            o[F4 + c] = make_float4(s.x * d.x, s.y * d.y, s.z * d.z, s.w * d.w);
+            o[2 * F4 + c] = make_float4(fabsf(s.x - d.x), fabsf(s.y - d.y), fabsf(s.z - d.z), fabsf(s.w - d.w));
+        }
+    }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }   // torch.abs' subgradient: 0 at 0
+
+__global__ __launch_bounds__(BLOCK) void lp_feat_bwd_kernel(const float4* __restrict__ gf, const float4* __restrict__ h,
+                                                            const int64_t* __restrict__ edges, float4* __restrict__ ghs,
+                                                            float4* __restrict__ ghd, int64_t N, int64_t K, int F4) {
+    const int lane = threadIdx.x % GMP_WAVE;
+    for (int64_t k = wave_id(); k < K; k += wave_count()) {
+        const int64_t a = edges[k], b = edges[K + k];
+        const bool ok = a >= 0 && a < N && b >= 0 && b < N;
+        for (int c = lane; c < F4; c += GMP_WAVE) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f), d = s;
+            if (ok) { s = h[a * F4 + c]; d = h[b * F4 + c]; }
+            const float4* g = gf + k * 3 * F4;
+            const float4 gs = g[c], gp = g[F4 + c], ga = g[2 * F4 + c];
+            float4 t = make_float4(ga.x * sgn(s.x - d.x), ga.y * sgn(s.y - d.y), ga.z * sgn(s.z - d.z), ga.w * sgn(s.w - d.w));
+            ghs[k * F4 + c] = make_float4(gs.x + gp.x * d.x + t.x, gs.y + gp.y * d.y + t.y, gs.z + gp.z * d.z + t.z, gs.w + gp.w * d.w + t.w);
+            ghd[k * F4 + c] = make_float4(gs.x + gp.x * s.x - t.x, gs.y + gp.y * s.y - t.y, gs.z + gp.z * s.z - t.z, gs.w + gp.w * s.w - t.w);
+        }
+    }
+}
+
+int grid_for(int64_t rows) {
+    int64_t b = (rows + WPB - 1) / WPB;
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (int)b;
+}
+
+int feat_ok(const char* who, int feat) {
+    if (feat <= 0 || feat % 4) return gmp::fail(GMP_ERR_ARG, "%s: feature width %d must be a positive multiple of 4", who, feat);
+    return GMP_OK;
+}
+
+}  // namespace
+
+extern "C" int gmp_row_gather(const float* src, const int64_t* idx, const int32_t* seg_ptr, float* out, int64_t M,
+                              int64_t num_src_rows, int feat, gmp_stream_t stream) {
+    if (int rc = feat_ok("row_gather", feat)) return rc;
+    if (M < 0 || num_src_rows < 0 || (M > 0 && (!src || !idx || !out))) return gmp::fail(GMP_ERR_ARG, "row_gather: bad argument");
+    if (M == 0) return GMP_OK;
+    hipLaunchKernelGGL(row_gather_kernel, dim3(grid_for(M)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)src, idx,
+                       seg_ptr, (float4*)out, M, num_src_rows, feat / 4);
+    return gmp::check_launch("row_gather_kernel");
+}
+
+extern "C" int gmp_segment_max_fwd(const float* x, const int32_t* ptr, float* out, int64_t B, int feat, gmp_stream_t stream) {
+    if (int rc = feat_ok("segment_max_fwd", feat)) return rc;
+    if (B < 0 || (B > 0 && (!x || !ptr || !out))) return gmp::fail(GMP_ERR_ARG, "segment_max_fwd: bad argument");
+    if (B == 0) return GMP_OK;
+    hipLaunchKernelGGL(seg_max_fwd_kernel, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)x, ptr,
+                       (float4*)out, B, feat / 4);
+    return gmp::check_launch("seg_max_fwd_kernel");
+}
+
+extern "C" int gmp_segment_max_bwd(const float* g_out, const float* x, const float* out, const int32_t* ptr, float* g_x,
+                                   int64_t B, int feat, gmp_stream_t stream) {
+    if (int rc = feat_ok("segment_max_bwd", feat)) return rc;
+    if (B < 0 || (B > 0 && (!g_out || !x || !out || !ptr || !g_x))) return gmp::fail(GMP_ERR_ARG, "segment_max_bwd: bad argument");
+    if (B == 0) return GMP_OK;
+    hipLaunchKernelGGL(seg_max_bwd_kernel, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)g_out,
+                       (const float4*)x, (const float4*)out, ptr, (float4*)g_x, B, feat / 4);
+    return gmp::check_launch("seg_max_bwd_kernel");
+}
+
+extern "C" int gmp_lp_edge_features_fwd(const float* h, const int64_t* edges, float* feat, int64_t N, int64_t K, int F,
+                                        gmp_stream_t stream) {
+    if (int rc = feat_ok("lp_edge_features_fwd", F)) return rc;
+    if (N < 0 || K < 0 || (K > 0 && (!h || !edges || !feat))) return gmp::fail(GMP_ERR_ARG, "lp_edge_features_fwd: bad argument");
+    if (K == 0) return GMP_OK;
+    hipLaunchKernelGGL(lp_feat_fwd_kernel, dim3(grid_for(K)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)h, edges,
+                       (float4*)feat, N, K, F / 4);
+    return gmp::check_launch("lp_feat_fwd_kernel");
+}
+
+extern "C" int gmp_lp_edge_features_bwd(const float* g_feat, const float* h, const int64_t* edges, float* g_hs, float* g_hd,
+                                        int64_t N, int64_t K, int F, gmp_stream_t stream) {
+    if (int rc = feat_ok("lp_edge_features_bwd", F)) return rc;
+    if (N < 0 || K < 0 || (K > 0 && (!g_feat || !h || !edges || !g_hs || !g_hd)))
+        return gmp::fail(GMP_ERR_ARG, "lp_edge_features_bwd: bad argument");
+    if (K == 0) return GMP_OK;
+    hipLaunchKernelGGL(lp_feat_bwd_kernel, dim3(grid_for(K)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)g_feat,
+                       (const float4*)h, edges, (float4*)g_hs, (float4*)g_hd, N, K, F / 4);
+    return gmp::check_launch("lp_feat_bwd_kernel");
+}

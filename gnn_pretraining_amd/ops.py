@@ -1,0 +1,302 @@
+"""Raw (non-autograd) wrappers: torch tensors in, one C-ABI call each.
+
+These check shapes/dtypes/devices on the host before the launch (a wrong shape
+must raise here, not fault on the GPU) and allocate outputs/workspaces with
+torch.  Autograd lives in operators.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _stream(t: Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> None:
+    if not t.is_cuda:
+        raise L.GnnmpError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback), got {t.device}")
+    if t.dtype != dtype:
+        raise L.GnnmpError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.GnnmpError(f"{name}: must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise L.GnnmpError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class CSR(NamedTuple):
+    """Both orientations of one edge_index (int32, device)."""
+    rowptr: Tensor     # [N+1] grouped by target
+    col: Tensor        # [E]   sources
+    perm: Tensor       # [E]   COO edge id per slot
+    rowptr_t: Tensor   # grouped by source (transposed graph)
+    col_t: Tensor
+    perm_t: Tensor
+    num_nodes: int
+    status: Tensor     # int32[1]: endpoints out of range (0 when well formed)
+
+
+def csr_build(edge_index: Tensor, num_nodes: int) -> CSR:
+    _need(edge_index, torch.int64, "edge_index", 2)
+    if edge_index.size(0) != 2:
+        raise L.GnnmpError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
+    E, dev = edge_index.size(1), edge_index.device
+    mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    out = CSR(mk(num_nodes + 1), mk(E), mk(E), mk(num_nodes + 1), mk(E), mk(E), num_nodes, mk(1))
+    l = L.lib()
+    ws = _ws(l.gmp_csr_build_workspace_bytes(num_nodes, E), dev)
+    L.check(l.gmp_csr_build(_ptr(edge_index), num_nodes, E, _ptr(out.rowptr), _ptr(out.col), _ptr(out.perm),
+                            _ptr(out.rowptr_t), _ptr(out.col_t), _ptr(out.perm_t), _ptr(out.status),
+                            _ptr(ws), ws.numel(), _stream(edge_index)), "gmp_csr_build")
+    return out
+
+
+def _feat_ok(x: Tensor, name: str) -> int:
+    _need(x, torch.float32, name, 2)
+    F = x.size(1)
+    if F % 4 or F > 1024:
+        raise L.GnnmpError(f"{name}: feature width {F} must be a multiple of 4 and <= 1024")
+    return F
+
+
+def gin_aggregate_fwd(x: Tensor, rowptr: Tensor, col: Tensor, eps: Tensor) -> Tensor:
+    F = _feat_ok(x, "x")
+    _need(rowptr, torch.int32, "rowptr", 1); _need(col, torch.int32, "col", 1); _need(eps, torch.float32, "eps")
+    if rowptr.numel() != x.size(0) + 1:
+        raise L.GnnmpError(f"rowptr has {rowptr.numel()} entries for {x.size(0)} rows")
+    out = torch.empty_like(x)
+    L.check(L.lib().gmp_gin_aggregate_fwd(_ptr(x), _ptr(rowptr), _ptr(col), _ptr(eps), _ptr(out), x.size(0), F,
+                                          _stream(x)), "gmp_gin_aggregate_fwd")
+    return out
+
+
+def gin_aggregate_bwd(g_out: Tensor, rowptr_t: Tensor, col_t: Tensor, eps: Tensor,
+                      x: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+    F = _feat_ok(g_out, "g_out")
+    _need(rowptr_t, torch.int32, "rowptr_t", 1); _need(col_t, torch.int32, "col_t", 1)
+    if rowptr_t.numel() != g_out.size(0) + 1:
+        raise L.GnnmpError("rowptr_t / g_out row mismatch")
+    g_x = torch.empty_like(g_out)
+    g_eps = None
+    if x is not None:
+        _feat_ok(x, "x")
+        if x.shape != g_out.shape:
+            raise L.GnnmpError("x / g_out shape mismatch")
+        g_eps = torch.empty(1, dtype=torch.float32, device=g_out.device)
+    l = L.lib()
+    ws = _ws(l.gmp_gin_aggregate_bwd_workspace_bytes(g_out.size(0), F), g_out.device)
+    L.check(l.gmp_gin_aggregate_bwd(_ptr(g_out), _ptr(rowptr_t), _ptr(col_t), _ptr(eps), _ptr(x), _ptr(g_x),
+                                    _ptr(g_eps), g_out.size(0), F, _ptr(ws), ws.numel(), _stream(g_out)),
+            "gmp_gin_aggregate_bwd")
+    return g_x, g_eps
+
+
+def segment_sum(src: Tensor, ptr: Tensor, idx: Optional[Tensor], mean: bool = False,
+                out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    F = _feat_ok(src, "src")
+    _need(ptr, torch.int32, "ptr", 1)
+    if idx is not None:
+        _need(idx, torch.int32, "idx", 1)
+    nseg = ptr.numel() - 1
+    if out is None:
+        out = torch.empty(nseg, F, dtype=torch.float32, device=src.device)
+        accumulate = False
+    L.check(L.lib().gmp_segment_sum(_ptr(src), _ptr(ptr), _ptr(idx), _ptr(out), nseg, F, int(mean), int(accumulate),
+                                    _stream(src)), "gmp_segment_sum")
+    return out
+
+
+def row_gather(src: Tensor, idx: Tensor, seg_ptr: Optional[Tensor] = None) -> Tensor:
+    F = _feat_ok(src, "src")
+    _need(idx, torch.int64, "idx", 1)
+    if seg_ptr is not None:
+        _need(seg_ptr, torch.int32, "seg_ptr", 1)
+        if seg_ptr.numel() != src.size(0) + 1:
+            raise L.GnnmpError("seg_ptr must have one entry per source row + 1")
+    out = torch.empty(idx.numel(), F, dtype=torch.float32, device=src.device)
+    L.check(L.lib().gmp_row_gather(_ptr(src), _ptr(idx), _ptr(seg_ptr), _ptr(out), idx.numel(), src.size(0), F,
+                                   _stream(src)), "gmp_row_gather")
+    return out
+
+
+def segment_max_fwd(x: Tensor, ptr: Tensor) -> Tensor:
+    F = _feat_ok(x, "x")
+    _need(ptr, torch.int32, "ptr", 1)
+    out = torch.empty(ptr.numel() - 1, F, dtype=torch.float32, device=x.device)
+    L.check(L.lib().gmp_segment_max_fwd(_ptr(x), _ptr(ptr), _ptr(out), ptr.numel() - 1, F, _stream(x)),
+            "gmp_segment_max_fwd")
+    return out
+
+
+def segment_max_bwd(g_out: Tensor, x: Tensor, out: Tensor, ptr: Tensor) -> Tensor:
+    F = _feat_ok(x, "x")
+    _need(g_out, torch.float32, "g_out", 2); _need(out, torch.float32, "out", 2); _need(ptr, torch.int32, "ptr", 1)
+    if g_out.shape != out.shape or out.size(0) != ptr.numel() - 1 or out.size(1) != F:
+        raise L.GnnmpError("segment_max_bwd: shape mismatch")
+    g_x = torch.empty_like(x)
+    L.check(L.lib().gmp_segment_max_bwd(_ptr(g_out), _ptr(x), _ptr(out), _ptr(ptr), _ptr(g_x), ptr.numel() - 1, F,
+                                        _stream(x)), "gmp_segment_max_bwd")
+    return g_x
+
+
+NT, NN, TN = 0, 1, 2
+
+
+def gemm(mode: int, A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None,
+         alpha: float = 1.0, accumulate: bool = False, relu: bool = False) -> Tensor:
+    """NT: A[M,K] B[N,K]^T ; NN: A[M,K] B[K,N] ; TN: A[K,M]^T B[K,N]."""
+    _need(A, torch.float32, "A", 2); _need(B, torch.float32, "B", 2)
+    if mode == NT:
+        M, K, N = A.size(0), A.size(1), B.size(0); kb = B.size(1)
+    elif mode == NN:
+        M, K, N = A.size(0), A.size(1), B.size(1); kb = B.size(0)
+    elif mode == TN:
+        M, K, N = A.size(1), A.size(0), B.size(1); kb = B.size(0)
+    else:
+        raise L.GnnmpError(f"gemm mode {mode}")
+    if kb != K:
+        raise L.GnnmpError(f"gemm: inner dims differ ({K} vs {kb}) for mode {mode}")
+    if bias is not None:
+        _need(bias, torch.float32, "bias", 1)
+        if bias.numel() != N:
+            raise L.GnnmpError("gemm: bias length")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+        accumulate = False
+    else:
+        _need(out, torch.float32, "out", 2)
+        if tuple(out.shape) != (M, N):
+            raise L.GnnmpError("gemm: out shape")
+    l = L.lib()
+    wsb = l.gmp_gemm_f32_workspace_bytes(mode, M, N, K)
+    ws = _ws(wsb, A.device) if wsb else None
+    L.check(l.gmp_gemm_f32(mode, _ptr(A), _ptr(B), _ptr(bias), _ptr(out), M, N, K, A.size(1), B.size(1), N,
+                           float(alpha), int(accumulate), int(relu), _ptr(ws), wsb, _stream(A)), "gmp_gemm_f32")
+    return out
+
+
+def colsum(A: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _need(A, torch.float32, "A", 2)
+    M, N = A.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=A.device)
+        accumulate = False
+    l = L.lib()
+    wsb = l.gmp_colsum_workspace_bytes(M, N)
+    ws = _ws(wsb, A.device)
+    L.check(l.gmp_colsum(_ptr(A), _ptr(out), M, N, N, int(accumulate), _ptr(ws), ws.numel(), _stream(A)), "gmp_colsum")
+    return out
+
+
+def make_bn_config(training: bool, relu: bool, dropout_p: float = 0.0, seed: int = 0, stream_id: int = 0,
+                   eps: float = 1e-5, momentum: float = 0.1) -> L.BnConfig:
+    return L.BnConfig(int(training), int(relu), eps, momentum, float(dropout_p), seed & (2 ** 64 - 1), stream_id)
+
+
+def bn_fwd(x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, max_seg_rows: int, gamma: Tensor, beta: Tensor,
+           running_mean: Optional[Tensor], running_var: Optional[Tensor], cfg: L.BnConfig):
+    """Returns (y, save_mean, save_rstd); the saved stats are None in eval mode."""
+    _need(x, torch.float32, "x", 2)
+    rows, Cc = x.shape
+    if residual is not None:
+        _need(residual, torch.float32, "residual", 2)
+        if residual.shape != x.shape:
+            raise L.GnnmpError("bn: residual shape")
+    _need(seg_ptr, torch.int32, "seg_ptr", 1)
+    S = seg_ptr.numel() - 1
+    for t, n in ((gamma, "gamma"), (beta, "beta")):
+        _need(t, torch.float32, n, 1)
+        if t.numel() != Cc:
+            raise L.GnnmpError(f"bn: {n} length")
+    y = torch.empty_like(x)
+    sm = sr = None
+    if cfg.training:
+        sm = torch.empty(S, Cc, dtype=torch.float32, device=x.device)
+        sr = torch.empty(S, Cc, dtype=torch.float32, device=x.device)
+    l = L.lib()
+    ws = _ws(l.gmp_bn_workspace_bytes(rows, Cc, S, max_seg_rows), x.device)
+    L.check(l.gmp_bn_fwd(_ptr(x), _ptr(residual), _ptr(seg_ptr), S, max_seg_rows, rows, Cc, _ptr(gamma), _ptr(beta),
+                         _ptr(running_mean), _ptr(running_var), _ptr(sm), _ptr(sr), _ptr(y), C.byref(cfg),
+                         _ptr(ws), ws.numel(), _stream(x)), "gmp_bn_fwd")
+    return y, sm, sr
+
+
+def bn_bwd(g_y: Tensor, x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, max_seg_rows: int, gamma: Tensor,
+           beta: Tensor, running_mean, running_var, save_mean, save_rstd, cfg: L.BnConfig, group_seg_ptr=None):
+    """Returns (g_u, g_gamma [G,C], g_beta [G,C]); group_seg_ptr: python list of segment offsets (default one group)."""
+    _need(g_y, torch.float32, "g_y", 2); _need(x, torch.float32, "x", 2)
+    rows, Cc = x.shape
+    S = seg_ptr.numel() - 1
+    grp = [0, S] if group_seg_ptr is None else list(group_seg_ptr)
+    G = len(grp) - 1
+    arr = (C.c_int32 * (G + 1))(*grp)
+    g_u = torch.empty_like(x)
+    gg = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
+    gb = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
+    l = L.lib()
+    ws = _ws(l.gmp_bn_workspace_bytes(rows, Cc, S, max_seg_rows), x.device)
+    L.check(l.gmp_bn_bwd(_ptr(g_y), _ptr(x), _ptr(residual), _ptr(seg_ptr), S, max_seg_rows, rows, Cc, _ptr(gamma),
+                         _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_rstd),
+                         _ptr(g_u), _ptr(gg), _ptr(gb), C.cast(arr, C.c_void_p), G, C.byref(cfg), _ptr(ws), ws.numel(),
+                         _stream(x)), "gmp_bn_bwd")
+    return g_u, gg, gb
+
+
+def lp_edge_features_fwd(h: Tensor, edges: Tensor) -> Tensor:
+    F = _feat_ok(h, "h")
+    _need(edges, torch.int64, "edges", 2)
+    K = edges.size(1)
+    feat = torch.empty(K, 3 * F, dtype=torch.float32, device=h.device)
+    L.check(L.lib().gmp_lp_edge_features_fwd(_ptr(h), _ptr(edges), _ptr(feat), h.size(0), K, F, _stream(h)),
+            "gmp_lp_edge_features_fwd")
+    return feat
+
+
+def lp_edge_features_bwd(g_feat: Tensor, h: Tensor, edges: Tensor) -> Tuple[Tensor, Tensor]:
+    F = _feat_ok(h, "h")
+    _need(g_feat, torch.float32, "g_feat", 2); _need(edges, torch.int64, "edges", 2)
+    K = edges.size(1)
+    if tuple(g_feat.shape) != (K, 3 * F):
+        raise L.GnnmpError("lp_edge_features_bwd: g_feat shape")
+    ghs = torch.empty(K, F, dtype=torch.float32, device=h.device)
+    ghd = torch.empty_like(ghs)
+    L.check(L.lib().gmp_lp_edge_features_bwd(_ptr(g_feat), _ptr(h), _ptr(edges), _ptr(ghs), _ptr(ghd), h.size(0), K, F,
+                                             _stream(h)), "gmp_lp_edge_features_bwd")
+    return ghs, ghd
+
+
+def nt_xent_fwd(z1: Tensor, z2: Tensor, temperature: float) -> Tuple[Tensor, Tensor]:
+    """Returns (loss_sum [1], workspace) -- the workspace feeds nt_xent_bwd."""
+    _need(z1, torch.float32, "z1", 2); _need(z2, torch.float32, "z2", 2)
+    if z1.shape != z2.shape:
+        raise L.GnnmpError("nt_xent: z1/z2 shapes differ")
+    n, d = z1.shape
+    l = L.lib()
+    ws = _ws(l.gmp_nt_xent_workspace_bytes(n, d), z1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=z1.device)
+    L.check(l.gmp_nt_xent_fwd(_ptr(z1), _ptr(z2), n, d, float(temperature), _ptr(loss), _ptr(ws), ws.numel(),
+                              _stream(z1)), "gmp_nt_xent_fwd")
+    return loss, ws
+
+
+def nt_xent_bwd(z1: Tensor, z2: Tensor, temperature: float, g_scale: Tensor, ws: Tensor) -> Tuple[Tensor, Tensor]:
+    n, d = z1.shape
+    _need(g_scale, torch.float32, "g_scale")
+    g1, g2 = torch.empty_like(z1), torch.empty_like(z2)
+    L.check(L.lib().gmp_nt_xent_bwd(_ptr(z1), _ptr(z2), n, d, float(temperature), _ptr(g_scale), _ptr(g1), _ptr(g2),
+                                    _ptr(ws), ws.numel(), _stream(z1)), "gmp_nt_xent_bwd")
+    return g1, g2

@@ -1,0 +1,200 @@
+/*
+ * libgnnmp -- MI355X (gfx950) message-passing kernels behind a flat C ABI.
+ *
+ * This is the drop-in boundary of the build.  The reference
+ * (alonbebchuk/GNN-Pretraining) has no FFI of its own: its hot path calls
+ * torch-geometric / torch operators from Python.  Each entry point below names the
+ * reference call site (file:line under /root/reference) whose operator it serves.
+ *
+ * Conventions
+ *   - every function returns GMP_OK (0) or a negative GMP_ERR_* code; the text of
+ *     the last error on the calling thread is at gmp_last_error_string();
+ *   - no exceptions cross the boundary, nothing here allocates or frees device
+ *     memory: the caller owns every buffer and passes a workspace where one is
+ *     needed (size from the matching *_workspace_bytes function);
+ *   - all pointers are DEVICE pointers unless a parameter says "host";
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*); no call synchronises;
+ *   - feature matrices are row-major fp32; graph indices handed over by the caller
+ *     are int64 (the reference's dtype), CSR arrays produced here are int32;
+ *   - F (feature width) must be a multiple of 4 and rows must be 16-byte aligned.
+ */
+#ifndef GNNMP_H
+#define GNNMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMP_OK 0
+#define GMP_ERR_ARG (-1)       /* bad argument (null pointer, negative size, bad alignment) */
+#define GMP_ERR_LAUNCH (-2)    /* HIP reported a launch/runtime error */
+#define GMP_ERR_WORKSPACE (-3) /* workspace too small */
+#define GMP_ERR_UNSUPPORTED (-4)
+
+typedef void* gmp_stream_t; /* hipStream_t */
+
+int gmp_version(void);
+const char* gmp_last_error_string(void);
+
+/* ------------------------------------------------------------------------- *
+ * Index build: COO int64 -> CSR int32, both orientations.
+ * Serves PyG MessagePassing.propagate's gather/scatter indexing for
+ * GINConv(h, edge_index) (src/models/gnn.py:41) and its backward.
+ *   edge_index  [2,E] int64, row 0 = source j, row 1 = target i (PyG flow).
+ *   rowptr/col/perm      grouped by TARGET: row i lists the sources of edges j->i
+ *   rowptr_t/col_t/perm_t grouped by SOURCE (transposed graph, for the backward);
+ *                         the three *_t pointers may all be NULL.
+ *   perm[k] = COO edge id stored at CSR slot k; within a row slots are in ascending
+ *   edge id (stable counting sort) -- bit-exact against oracle.graph_ops.coo_to_csr.
+ *   status      device int32[1]: number of endpoints outside [0,N) (those edges are
+ *               dropped instead of faulting); 0 on well-formed input.
+ * ------------------------------------------------------------------------- */
+size_t gmp_csr_build_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int gmp_csr_build(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
+                  int32_t* rowptr, int32_t* col, int32_t* perm,
+                  int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t,
+                  int32_t* status, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * GIN neighbourhood aggregation (the SpMM-style kernel of BASELINE.json).
+ *   fwd: out[i,:] = (1 + eps) * x[i,:] + sum_{k in rowptr[i]..rowptr[i+1]} x[col[k],:]
+ *        == PyG GINConv before its nn (src/models/gnn.py:29-41).
+ *   bwd: g_x[i,:] = (1 + eps) * g_out[i,:] + sum over the TRANSPOSED CSR of g_out;
+ *        g_eps[0] = sum_i <g_out[i,:], x[i,:]>  (deterministic two-stage reduction).
+ *   eps is a device float[1] (the learnable GINConv.eps, shape [1]).
+ * Algorithmic bytes per launch: 2*4*F*N + 4*(N+1) + 4*E.
+ * ------------------------------------------------------------------------- */
+int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, const int32_t* col, const float* eps,
+                          float* out, int64_t num_nodes, int feat, gmp_stream_t stream);
+size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t num_nodes, int feat);
+int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t, const float* eps,
+                          const float* x, float* g_x, float* g_eps, int64_t num_nodes, int feat,
+                          void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Generic segmented row sum:  out[r,:] (+)= scale_r * sum_{k in ptr[r]..ptr[r+1]} src[idx ? idx[k] : k, :]
+ *   mean != 0  -> scale_r = 1 / max(ptr[r+1]-ptr[r], 1)   (PyG scatter 'mean')
+ * Serves global_mean_pool (src/pretrain/tasks.py:241,244,299,331; finetune_model.py:75)
+ * and the scatter-add backward of row gathers h[idx] (tasks.py:80, heads.py:59-60).
+ * ------------------------------------------------------------------------- */
+int gmp_segment_sum(const float* src, const int32_t* ptr, const int32_t* idx, float* out,
+                    int64_t num_segments, int feat, int mean, int accumulate, gmp_stream_t stream);
+
+/* out[m,:] = scale_m * src[idx[m],:];  scale_m = 1, or 1/max(count[idx[m]],1) when
+ * seg_ptr != NULL (backward of global_mean_pool: idx = batch vector). idx int64. */
+int gmp_row_gather(const float* src, const int64_t* idx, const int32_t* seg_ptr, float* out,
+                   int64_t num_out_rows, int64_t num_src_rows, int feat, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * global_max_pool (tasks.py:242,245): out[b,f] = max over rows ptr[b]..ptr[b+1];
+ * empty segment -> 0 (PyG: new_zeros + scatter_reduce amax, include_self=False).
+ * bwd splits g evenly between tied maxima, as torch's scatter_reduce('amax') does.
+ * ------------------------------------------------------------------------- */
+int gmp_segment_max_fwd(const float* x, const int32_t* ptr, float* out, int64_t num_segments, int feat,
+                        gmp_stream_t stream);
+int gmp_segment_max_bwd(const float* g_out, const float* x, const float* out, const int32_t* ptr,
+                        float* g_x, int64_t num_segments, int feat, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32), C = alpha * op(A) op(B) (+ bias)(+ C).
+ * nn.Linear forward / input-grad / weight-grad of the GIN MLP and the heads
+ * (gnn.py:14,31,34; heads.py:42).
+ *   GMP_GEMM_NT: C[M,N] = A[M,K] * B[N,K]^T      (Linear forward: x W^T)
+ *   GMP_GEMM_NN: C[M,N] = A[M,K] * B[K,N]        (input grad: g W)
+ *   GMP_GEMM_TN: C[M,N] = A[K,M]^T * B[K,N]      (weight grad: g^T x), reduction over rows
+ *   bias: NULL or [N], added to every row.  accumulate != 0 -> C += result.
+ *   relu != 0 -> C = max(C, 0) after bias (MLPHead hidden layers).
+ * ------------------------------------------------------------------------- */
+#define GMP_GEMM_NT 0
+#define GMP_GEMM_NN 1
+#define GMP_GEMM_TN 2
+/* workspace: optional; when the output tile count cannot fill the chip and K is long
+ * (weight gradients) the kernel splits K over blockIdx.z into this buffer and sums the
+ * slices in order (deterministic).  0 bytes / NULL -> no split-K. */
+size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gmp_gemm_f32(int mode, const float* A, const float* B, const float* bias, float* C,
+                 int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                 float alpha, int accumulate, int relu, void* workspace, size_t workspace_bytes,
+                 gmp_stream_t stream);
+/* column sums: out[n] (+)= sum_m A[m,n]  (bias gradient), rows [0,M) */
+size_t gmp_colsum_workspace_bytes(int64_t M, int64_t N);
+int gmp_colsum(const float* A, float* out, int64_t M, int64_t N, int64_t lda, int accumulate,
+               void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Segment-wise BatchNorm1d (+ residual, ReLU, dropout) -- gnn.py:15,19-22,32,38,42-43.
+ * A "segment" is one reference forward() call's worth of rows: statistics are
+ * taken per segment so several independent forwards can share one launch.
+ *   seg_ptr     device int32 [S+1] row offsets; max_seg_rows = host-side max length.
+ *   training:   mean/biased var over the segment (eps 1e-5), saved to save_mean /
+ *               save_rstd [S,C]; running_mean/var (nullable) are updated segment by
+ *               segment in order with momentum 0.1 and the unbiased variance,
+ *               num_batches_tracked is the caller's business.
+ *   eval:       uses running_mean / running_var.
+ *   y = dropout(relu?( gamma * (x [+ residual] - mean) * rstd + beta ))
+ *   dropout keep-mask comes from Philox(seed, stream_id, element) and is NOT stored:
+ *   the backward regenerates it.  p = 0 disables dropout.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int training;        /* batch statistics vs running statistics */
+    int relu;            /* apply ReLU after the affine transform */
+    float eps;           /* 1e-5 */
+    float momentum;      /* 0.1 */
+    float dropout_p;     /* 0 = none */
+    uint64_t seed;       /* dropout seed */
+    uint32_t stream_id;  /* distinct per dropout site */
+} gmp_bn_config;
+
+size_t gmp_bn_workspace_bytes(int64_t rows, int channels, int num_segments, int64_t max_seg_rows);
+int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, int num_segments,
+               int64_t max_seg_rows, int64_t rows, int channels,
+               const float* gamma, const float* beta, float* running_mean, float* running_var,
+               float* save_mean, float* save_rstd, float* y,
+               const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+/* backward: given g_y, the BN input u = x (+ residual, recomputed on the fly), saved stats.
+ *   g_u [rows,C]   gradient w.r.t. the BN input (also the residual's gradient)
+ *   g_gamma/g_beta [G,C] per parameter-group sums; group g covers segments
+ *   grp_seg_ptr[g]..grp_seg_ptr[g+1] (host int32 [G+1]); G=1 -> ordinary gradients. */
+int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr, int num_segments,
+               int64_t max_seg_rows, int64_t rows, int channels,
+               const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               const float* save_mean, const float* save_rstd,
+               float* g_u, float* g_gamma, float* g_beta, const int32_t* grp_seg_ptr_host, int num_groups,
+               const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Link-prediction edge features (the per-edge MLP input, heads.py:58-66):
+ *   feat[k,:] = [ hs+hd | hs*hd | |hs-hd| ],  hs = h[edges[0,k]], hd = h[edges[1,k]]
+ * bwd produces per-edge gradients g_hs, g_hd [K,F]; the caller reduces them onto
+ * nodes with gmp_segment_sum over a CSR of the decoder edges.
+ * ------------------------------------------------------------------------- */
+int gmp_lp_edge_features_fwd(const float* h, const int64_t* edges, float* feat, int64_t num_nodes,
+                             int64_t num_edges, int feat_dim, gmp_stream_t stream);
+int gmp_lp_edge_features_bwd(const float* g_feat, const float* h, const int64_t* edges, float* g_hs,
+                             float* g_hd, int64_t num_nodes, int64_t num_edges, int feat_dim,
+                             gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * NT-Xent / InfoNCE (tasks.py:192-213, 265-287).
+ *   z = [normalize(z1); normalize(z2)]  (eps 1e-12), sim = z z^T / T, diag = -inf,
+ *   loss_sum = sum_i CE(sim[i,:], pos_i),  pos_i = (i + n) mod 2n.
+ * fwd writes loss_sum (device float[1]); bwd returns d loss_sum / d z1, d z2 scaled
+ * by `g_scale` (device float[1], the upstream gradient).  n <= 8192.
+ * An index outside [0, num_src_rows) in gmp_row_gather / gmp_lp_edge_features_* reads
+ * as a zero row instead of faulting.
+ * ------------------------------------------------------------------------- */
+size_t gmp_nt_xent_workspace_bytes(int64_t n, int dim);
+int gmp_nt_xent_fwd(const float* z1, const float* z2, int64_t n, int dim, float temperature,
+                    float* loss_sum, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+int gmp_nt_xent_bwd(const float* z1, const float* z2, int64_t n, int dim, float temperature,
+                    const float* g_scale, float* g_z1, float* g_z2,
+                    void* workspace /* the one fwd filled */, size_t workspace_bytes, gmp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNMP_H */

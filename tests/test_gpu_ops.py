@@ -1,0 +1,292 @@
+"""Operator-level parity: each C-ABI kernel vs the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): indices bit-exact; fp32 within 1e-4 relative.
+Relative error is measured against the tensor's max magnitude (a per-element relative
+test is meaningless next to exact zeros produced by ReLU).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gnn_pretraining_amd import ops, synthetic as S          # noqa: E402
+from oracle import graph_ops as OG                            # noqa: E402
+
+DEV = "cuda:0"
+RTOL = 1e-4
+
+
+def close(got, want, rtol=RTOL, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    scale = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item() / scale
+    assert err <= rtol, f"{what}: max rel err {err:.3e} > {rtol}"
+
+
+def rand_edges(gen, n, e):
+    return torch.randint(0, n, (2, e), generator=gen)
+
+
+# ------------------------------------------------------------------ csr_build
+@pytest.mark.parametrize("n,e", [(1, 0), (5, 0), (7, 3), (264, 992), (300, 5000), (16384, 60000),
+                                 (16385, 70000), (50000, 400000), (2708, 10858)])
+def test_csr_build_bit_exact(n, e):
+    gen = torch.Generator().manual_seed(n * 7 + e)
+    ei = rand_edges(gen, n, e) if e else torch.empty(2, 0, dtype=torch.long)
+    csr = ops.csr_build(ei.to(DEV), n)
+    torch.cuda.synchronize()
+    assert int(csr.status.item()) == 0
+    for by, (rp, col, perm) in (("dst", (csr.rowptr, csr.col, csr.perm)), ("src", (csr.rowptr_t, csr.col_t, csr.perm_t))):
+        orp, ocol, operm = OG.coo_to_csr(ei, n, by)
+        assert torch.equal(rp.cpu(), orp), f"rowptr {by}"
+        assert torch.equal(perm.cpu(), operm), f"perm {by}"
+        assert torch.equal(col.cpu(), ocol), f"col {by}"
+
+
+def test_csr_build_high_degree_rows():
+    # star graph: one hub with degree 5000 (exercises the wave-cooperative row ordering)
+    n = 6000
+    hub = torch.zeros(5000, dtype=torch.long)
+    leaves = torch.arange(1, 5001)
+    ei = torch.cat([torch.stack([hub, leaves]), torch.stack([leaves, hub])], dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), generator=torch.Generator().manual_seed(3))]
+    csr = ops.csr_build(ei.to(DEV), n)
+    for by, (rp, col, perm) in (("dst", (csr.rowptr, csr.col, csr.perm)), ("src", (csr.rowptr_t, csr.col_t, csr.perm_t))):
+        orp, ocol, operm = OG.coo_to_csr(ei, n, by)
+        assert torch.equal(rp.cpu(), orp) and torch.equal(perm.cpu(), operm) and torch.equal(col.cpu(), ocol)
+
+
+def test_csr_build_reports_bad_endpoints():
+    ei = torch.tensor([[0, 1, 9, 2], [1, -1, 0, 0]])
+    csr = ops.csr_build(ei.to(DEV), 3)
+    assert int(csr.status.item()) == 2
+    assert csr.rowptr.cpu().tolist() == [0, 1, 2, 2]        # only edges 0->1 and 2->0 survive
+
+
+# ------------------------------------------------------------ gin aggregation
+@pytest.mark.parametrize("graphs,F", [(1, 256), (8, 256), (32, 256), (8, 128), (8, 512), (8, 64), (3, 1024)])
+def test_gin_aggregate_fwd_bwd(graphs, F):
+    gen = torch.Generator().manual_seed(graphs * 1000 + F)
+    b = S.domain_batch(gen, 21, graphs)
+    n = b.num_nodes
+    x = torch.randn(n, F, generator=gen)
+    eps = torch.tensor([0.37])
+    g = torch.randn(n, F, generator=gen)
+    xr, er = x.clone().requires_grad_(), eps.clone().requires_grad_()
+    want = OG.gin_aggregate(xr, b.edge_index, er)
+    want.backward(g)
+    csr = ops.csr_build(b.edge_index.to(DEV), n)
+    xd, ed, gd = x.to(DEV), eps.to(DEV), g.to(DEV)
+    out = ops.gin_aggregate_fwd(xd, csr.rowptr, csr.col, ed)
+    close(out, want, what="aggregate fwd")
+    gx, ge = ops.gin_aggregate_bwd(gd, csr.rowptr_t, csr.col_t, ed, xd)
+    close(gx, xr.grad, what="aggregate g_x")
+    close(ge, er.grad, what="aggregate g_eps")
+
+
+def test_gin_aggregate_isolated_and_empty():
+    x = torch.randn(5, 256)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    csr = ops.csr_build(ei.to(DEV), 5)
+    out = ops.gin_aggregate_fwd(x.to(DEV), csr.rowptr, csr.col, torch.zeros(1, device=DEV))
+    close(out, OG.gin_aggregate(x, ei, torch.zeros(1)))
+    # no edges at all
+    e0 = torch.empty(2, 0, dtype=torch.long)
+    csr = ops.csr_build(e0.to(DEV), 5)
+    out = ops.gin_aggregate_fwd(x.to(DEV), csr.rowptr, csr.col, torch.ones(1, device=DEV))
+    close(out, 2 * x)
+
+
+def test_gin_aggregate_cora_shape_and_linearity():
+    gen = torch.Generator().manual_seed(5)
+    c = S.cora_like(gen, dim=16)
+    n = c.num_nodes
+    x, y = torch.randn(n, 256, generator=gen), torch.randn(n, 256, generator=gen)
+    csr = ops.csr_build(c.edge_index.to(DEV), n)
+    eps = torch.tensor([0.1], device=DEV)
+    f = lambda t: ops.gin_aggregate_fwd(t.to(DEV), csr.rowptr, csr.col, eps)
+    close(f(x), OG.gin_aggregate(x, c.edge_index, torch.tensor([0.1])), what="cora aggregate")
+    close(f(2 * x + y), 2 * f(x) + f(y), what="linearity")       # size-independent property
+
+
+# ------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("graphs,F", [(1, 256), (8, 256), (16, 512)])
+def test_mean_and_max_pool(graphs, F):
+    gen = torch.Generator().manual_seed(graphs + F)
+    b = S.domain_batch(gen, 21, graphs)
+    x = torch.relu(torch.randn(b.num_nodes, F, generator=gen))     # post-ReLU: many tied zeros
+    x[:, :7] = 0.0                                                 # columns where EVERY node ties at 0
+    g = torch.randn(graphs, F, generator=gen)
+    ptr = torch.tensor(b.ptr_host, dtype=torch.int32, device=DEV)
+    xd, gd = x.to(DEV), g.to(DEV)
+    # mean
+    xr = x.clone().requires_grad_()
+    want = OG.global_mean_pool(xr, b.batch); want.backward(g)
+    close(ops.segment_sum(xd, ptr, None, mean=True), want, what="mean pool")
+    close(ops.row_gather(gd, b.batch.to(DEV), ptr), xr.grad, what="mean pool bwd")
+    # max (+ tie rule)
+    xr = x.clone().requires_grad_()
+    want = OG.global_max_pool(xr, b.batch); want.backward(g)
+    out = ops.segment_max_fwd(xd, ptr)
+    close(out, want, what="max pool")
+    close(ops.segment_max_bwd(gd, xd, out, ptr), xr.grad, what="max pool bwd (even split between ties)")
+
+
+def test_row_gather_and_scatter_add_backward():
+    gen = torch.Generator().manual_seed(11)
+    n, F, m = 300, 256, 700
+    x = torch.randn(n, F, generator=gen)
+    idx = torch.randint(0, n, (m,), generator=gen)                 # repeats: backward must accumulate
+    g = torch.randn(m, F, generator=gen)
+    xr = x.clone().requires_grad_()
+    xr[idx].backward(g)
+    close(ops.row_gather(x.to(DEV), idx.to(DEV)), x[idx], what="gather")
+    # scatter-add backward = segmented sum over a CSR of (row -> gathered positions)
+    ei = torch.stack([torch.arange(m), idx])                       # "edge" k -> idx[k]
+    csr = ops.csr_build(ei.to(DEV), max(n, m))
+    gx = ops.segment_sum(g.to(DEV), csr.rowptr[: n + 1].contiguous(), csr.col)
+    close(gx, xr.grad, what="gather bwd")
+
+
+# ----------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(264, 512, 256), (264, 256, 512), (1, 1, 1), (33, 7, 21), (300, 256, 37),
+                                   (1000, 256, 768), (2708, 256, 1433), (6700, 512, 256), (40000, 512, 256),
+                                   (65, 130, 67)])
+def test_gemm_modes(M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen)
+    bias = torch.randn(N, generator=gen)
+    G = torch.randn(M, N, generator=gen)
+    Ad, Wd, Gd = A.to(DEV), W.to(DEV), G.to(DEV)
+    ref = lambda a, b: (a.double() @ b.double()).float()
+    close(ops.gemm(ops.NT, Ad, Wd, bias.to(DEV)), ref(A, W.t()) + bias, what="NT + bias")
+    close(ops.gemm(ops.NT, Ad, Wd, bias.to(DEV), relu=True), torch.relu(ref(A, W.t()) + bias), what="NT + bias + relu")
+    close(ops.gemm(ops.NN, Gd, Wd), ref(G, W), what="NN (input grad)")
+    close(ops.gemm(ops.TN, Gd, Ad), ref(G.t(), A), what="TN (weight grad, split-K)")
+    acc = torch.randn(N, K, generator=gen)
+    close(ops.gemm(ops.TN, Gd, Ad, out=acc.to(DEV).clone(), alpha=0.5, accumulate=True), acc + 0.5 * ref(G.t(), A),
+          what="TN accumulate")
+    close(ops.colsum(Gd), G.double().sum(0).float(), what="colsum")
+
+
+def test_gemm_rejects_bad_shapes():
+    from gnn_pretraining_amd._lib import GnnmpError
+    a = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(GnnmpError):
+        ops.gemm(ops.NT, a, torch.zeros(5, 9, device=DEV))
+    with pytest.raises(GnnmpError):
+        ops.gemm(ops.NT, a.cpu(), a.cpu())
+
+
+# ------------------------------------------------------------------ BatchNorm
+def _bn_oracle(x, res, seg, gamma, beta, rm, rv, training, relu):
+    """Per-segment torch batch_norm, segments in order (== S separate module calls)."""
+    import torch.nn.functional as F
+    outs = []
+    for a, b in zip(seg[:-1], seg[1:]):
+        u = x[a:b] + (res[a:b] if res is not None else 0)
+        y = F.batch_norm(u, rm, rv, gamma, beta, training=training, momentum=0.1, eps=1e-5)
+        outs.append(torch.relu(y) if relu else y)
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("seg,C,relu,with_res", [([0, 264], 256, True, False), ([0, 40, 300, 301 + 30, 600], 512, True, True),
+                                                 ([0, 2708], 256, True, True), ([0, 1500, 1500 + 700], 64, False, False),
+                                                 ([0, 2, 5], 128, True, False)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_fwd_bwd(seg, C, relu, with_res, training):
+    gen = torch.Generator().manual_seed(sum(seg) + C)
+    rows = seg[-1]
+    x = torch.randn(rows, C, generator=gen) * 2 + 0.5
+    res = torch.randn(rows, C, generator=gen) if with_res else None
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    rm0, rv0 = torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5
+    gy = torch.randn(rows, C, generator=gen)
+    # oracle
+    xr = x.clone().requires_grad_()
+    rr = res.clone().requires_grad_() if with_res else None
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rm, rv = rm0.clone(), rv0.clone()
+    want = _bn_oracle(xr, rr, seg, gr, br, rm, rv, training, relu)
+    want.backward(gy)
+    # HIP
+    d = lambda t: None if t is None else t.to(DEV)
+    segd = torch.tensor(seg, dtype=torch.int32, device=DEV)
+    mx = max(b - a for a, b in zip(seg[:-1], seg[1:]))
+    rmd, rvd = d(rm0.clone()), d(rv0.clone())
+    cfg = ops.make_bn_config(training, relu)
+    y, sm, sr = ops.bn_fwd(d(x), d(res), segd, mx, d(gamma), d(beta), rmd, rvd, cfg)
+    close(y, want, what="bn fwd")
+    close(rmd, rm, what="running_mean"); close(rvd, rv, what="running_var")
+    gu, gg, gb = ops.bn_bwd(d(gy), d(x), d(res), segd, mx, d(gamma), d(beta), rmd, rvd, sm, sr, cfg)
+    close(gu, xr.grad, rtol=2e-4, what="bn g_x")
+    if with_res:
+        close(gu, rr.grad, rtol=2e-4, what="bn g_residual")
+    close(gg[0], gr.grad, rtol=2e-4, what="bn g_gamma"); close(gb[0], br.grad, rtol=2e-4, what="bn g_beta")
+
+
+def test_bn_param_grad_groups_and_dropout_consistency():
+    gen = torch.Generator().manual_seed(9)
+    seg = [0, 100, 220, 300, 450]
+    C = 256
+    x = torch.randn(seg[-1], C, generator=gen)
+    gy = torch.randn(seg[-1], C, generator=gen)
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    d = lambda t: t.to(DEV)
+    segd = torch.tensor(seg, dtype=torch.int32, device=DEV)
+    cfg = ops.make_bn_config(True, True, dropout_p=0.2, seed=1234, stream_id=3)
+    y, sm, sr = ops.bn_fwd(d(x), None, segd, 150, d(gamma), d(beta), None, None, cfg)
+    y2, _, _ = ops.bn_fwd(d(x), None, segd, 150, d(gamma), d(beta), None, None, cfg)
+    assert torch.equal(y, y2)                                      # counter-based mask is reproducible
+    cfg0 = ops.make_bn_config(True, True)
+    y0, _, _ = ops.bn_fwd(d(x), None, segd, 150, d(gamma), d(beta), None, None, cfg0)
+    kept = (y != 0)
+    close(y[kept], (y0 / 0.8)[kept], what="kept elements are scaled by 1/(1-p)")
+    frac = 1.0 - (y != 0).sum().item() / max((y0 != 0).sum().item(), 1)
+    assert 0.17 < frac < 0.23, f"drop fraction {frac}"
+    # backward regenerates the same mask: gradient is zero exactly where the output was dropped
+    gu, gg2, gb2 = ops.bn_bwd(d(gy), d(x), None, segd, 150, d(gamma), d(beta), None, None, sm, sr, cfg, [0, 1, 4])
+    gu1, gg1, gb1 = ops.bn_bwd(d(gy), d(x), None, segd, 150, d(gamma), d(beta), None, None, sm, sr, cfg)
+    close(gg2.sum(0), gg1[0], what="group sums add up (gamma)")
+    close(gb2.sum(0), gb1[0], what="group sums add up (beta)")
+    assert torch.equal(gu, gu1)
+
+
+# -------------------------------------------------------- LP edge features
+def test_lp_edge_features():
+    gen = torch.Generator().manual_seed(21)
+    n, K, F = 264, 2000, 256
+    h = torch.relu(torch.randn(n, F, generator=gen))               # zeros -> |hs-hd| hits its kink
+    edges = torch.randint(0, n, (2, K), generator=gen)
+    edges[:, :5] = torch.tensor([[3, 3, 3, 3, 3], [3, 3, 3, 3, 3]])  # self pairs: hs == hd exactly
+    g = torch.randn(K, 3 * F, generator=gen)
+    hr = h.clone().requires_grad_()
+    hs, hd = hr[edges[0]], hr[edges[1]]
+    want = torch.cat([hs + hd, hs * hd, (hs - hd).abs()], dim=1)
+    want.backward(g)
+    feat = ops.lp_edge_features_fwd(h.to(DEV), edges.to(DEV))
+    close(feat, want, what="lp features")
+    ghs, ghd = ops.lp_edge_features_bwd(g.to(DEV), h.to(DEV), edges.to(DEV))
+    # reduce onto nodes through CSRs of the decoder edges
+    csr = ops.csr_build(edges.to(DEV), n)
+    gh = ops.segment_sum(ghs, csr.rowptr_t, csr.perm_t)            # by source
+    gh = ops.segment_sum(ghd, csr.rowptr, csr.perm, out=gh, accumulate=True)   # by target
+    close(gh, hr.grad, what="lp features bwd")
+
+
+# ------------------------------------------------------------------ NT-Xent
+@pytest.mark.parametrize("n,d,T", [(8, 128, 0.5), (170, 128, 0.5), (333, 128, 0.2), (1, 128, 0.5), (2, 4, 1.0)])
+def test_nt_xent(n, d, T):
+    from oracle.tasks import nt_xent
+    gen = torch.Generator().manual_seed(n + d)
+    z1, z2 = torch.randn(n, d, generator=gen), torch.randn(n, d, generator=gen)
+    a, b = z1.clone().requires_grad_(), z2.clone().requires_grad_()
+    if n == 1:
+        pytest.skip("2x2 similarity: both rows have a single admissible column, loss is identically 0")
+    want, size = nt_xent(a, b, T)
+    (want * 0.25).backward()
+    loss, ws = ops.nt_xent_fwd(z1.to(DEV), z2.to(DEV), T)
+    close(loss, want.reshape(1), what="nt_xent loss")
+    g1, g2 = ops.nt_xent_bwd(z1.to(DEV), z2.to(DEV), T, torch.tensor([0.25], device=DEV), ws)
+    close(g1, a.grad, rtol=2e-4, what="nt_xent g_z1"); close(g2, b.grad, rtol=2e-4, what="nt_xent g_z2")
