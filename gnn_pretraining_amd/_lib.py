@@ -76,6 +76,18 @@ _SIGS: Dict[str, tuple] = {
     "gmp_nt_xent_workspace_bytes": (sz, [i64, i32]),
     "gmp_nt_xent_fwd": (C.c_int, [p, p, i64, i32, f32, p, p, sz, p]),
     "gmp_nt_xent_bwd": (C.c_int, [p, p, i64, i32, f32, p, p, p, p, sz, p]),
+    "gmp_dropout_fwd": (C.c_int, [p, p, i64, f32, C.c_uint64, C.c_uint32, p]),
+    "gmp_relu_dropout_bwd": (C.c_int, [p, p, p, i64, f32, C.c_uint64, C.c_uint32, p]),
+    "gmp_loss_workspace_bytes": (sz, [i64]),
+    "gmp_mse_sum_fwd": (C.c_int, [p, p, i64, p, p, sz, p]),
+    "gmp_mse_sum_bwd": (C.c_int, [p, p, p, p, i64, p]),
+    "gmp_sigmoid_fwd": (C.c_int, [p, p, i64, p]),
+    "gmp_sigmoid_bwd": (C.c_int, [p, p, p, i64, p]),
+    "gmp_bce_sum_fwd": (C.c_int, [p, p, i64, p, p, sz, p]),
+    "gmp_bce_sum_bwd": (C.c_int, [p, p, p, p, i64, p]),
+    "gmp_cross_entropy_sum_fwd": (C.c_int, [p, p, i64, i32, p, p, sz, p]),
+    "gmp_cross_entropy_sum_bwd": (C.c_int, [p, p, i64, i32, p, p, p]),
+    "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),
 }
 
 

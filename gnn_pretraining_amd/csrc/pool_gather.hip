@@ -49,7 +49,11 @@ __global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __rest
     }
 }
 
-// torch scatter_reduce('amax') backward: gradient split evenly between tied maxima
+// torch scatter_reduce('amax') backward: gradient split evenly between tied maxima.
+// Quirk reproduced on purpose: PyG calls it on a zero-initialised output with
+// include_self=False, and torch still counts that initial 0 as one more tie when the
+// segment maximum equals 0 (N_to_distribute = (self == result) + #ties).  After ReLU
+// whole columns are 0, so this matters: such a column gets g / (n + 1), not g / n.
 __global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
                                                             const float4* __restrict__ mx, const int* __restrict__ ptr,
                                                             float4* __restrict__ gx, int64_t B, int F4) {
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __rest
         const int s = ptr[b], e = ptr[b + 1];
         for (int c = lane; c < F4; c += GMP_WAVE) {
             const float4 m = mx[b * F4 + c], gg = g[b * F4 + c];
-            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 n = make_float4(m.x == 0.f, m.y == 0.f, m.z == 0.f, m.w == 0.f);
             for (int r = s; r < e; ++r) {
                 float4 v = x[(int64_t)r * F4 + c];
                 n.x += v.x == m.x; n.y += v.y == m.y; n.z += v.z == m.z; n.w += v.w == m.w;

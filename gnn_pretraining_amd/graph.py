@@ -99,8 +99,21 @@ class Batch:
 
     def to(self, device) -> "Batch":
         m = lambda t: None if t is None else t.to(device, non_blocking=True)
-        return Batch(m(self.x), m(self.edge_index), m(self.batch), m(self.ptr), self.ptr_host, self.edge_ptr_host,
-                     m(self.y), m(self.graph_properties))
+        out = Batch(m(self.x), m(self.edge_index), m(self.batch), m(self.ptr), self.ptr_host, self.edge_ptr_host,
+                    m(self.y), m(self.graph_properties))
+        if self.x.device.type == "cpu":
+            out._cache["host"] = self        # index work (augmentation, sampling) stays on the host copy
+        return out
+
+    def host(self) -> "Batch":
+        """The CPU twin of this batch (kept when the batch was moved with .to(); otherwise one D2H copy)."""
+        if self.x.device.type == "cpu":
+            return self
+        if "host" not in self._cache:
+            m = lambda t: None if t is None else t.cpu()
+            self._cache["host"] = Batch(m(self.x), m(self.edge_index), m(self.batch), m(self.ptr), self.ptr_host,
+                                        self.edge_ptr_host, m(self.y), m(self.graph_properties))
+        return self._cache["host"]
 
     # ---- HIP-path extras -----------------------------------------------------------
     @property

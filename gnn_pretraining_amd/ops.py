@@ -300,3 +300,104 @@ def nt_xent_bwd(z1: Tensor, z2: Tensor, temperature: float, g_scale: Tensor, ws:
     L.check(L.lib().gmp_nt_xent_bwd(_ptr(z1), _ptr(z2), n, d, float(temperature), _ptr(g_scale), _ptr(g1), _ptr(g2),
                                     _ptr(ws), ws.numel(), _stream(z1)), "gmp_nt_xent_bwd")
     return g1, g2
+
+
+def dropout_fwd(x: Tensor, p: float, seed: int, stream_id: int) -> Tensor:
+    _need(x, torch.float32, "x")
+    if x.numel() % 4:
+        raise L.GnnmpError("dropout: numel must be a multiple of 4")
+    y = torch.empty_like(x)
+    L.check(L.lib().gmp_dropout_fwd(_ptr(x), _ptr(y), x.numel(), float(p), seed & (2 ** 64 - 1), stream_id, _stream(x)),
+            "gmp_dropout_fwd")
+    return y
+
+
+def relu_dropout_bwd(g: Tensor, act: Tensor, p: float, seed: int, stream_id: int) -> Tensor:
+    _need(g, torch.float32, "g"); _need(act, torch.float32, "act")
+    if g.shape != act.shape or g.numel() % 4:
+        raise L.GnnmpError("relu_dropout_bwd: shapes")
+    out = torch.empty_like(g)
+    L.check(L.lib().gmp_relu_dropout_bwd(_ptr(g), _ptr(act), _ptr(out), g.numel(), float(p), seed & (2 ** 64 - 1),
+                                         stream_id, _stream(g)), "gmp_relu_dropout_bwd")
+    return out
+
+
+def _loss_ws(n: int, device) -> Tensor:
+    return _ws(L.lib().gmp_loss_workspace_bytes(n), device)
+
+
+def mse_sum_fwd(a: Tensor, b: Tensor) -> Tensor:
+    _need(a, torch.float32, "a"); _need(b, torch.float32, "b")
+    if a.shape != b.shape:
+        raise L.GnnmpError(f"mse_sum: shapes {tuple(a.shape)} vs {tuple(b.shape)}")
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = _loss_ws(a.numel(), a.device)
+    L.check(L.lib().gmp_mse_sum_fwd(_ptr(a), _ptr(b), a.numel(), _ptr(loss), _ptr(ws), ws.numel(), _stream(a)), "gmp_mse_sum_fwd")
+    return loss
+
+
+def mse_sum_bwd(a: Tensor, b: Tensor, g_scale: Tensor) -> Tensor:
+    ga = torch.empty_like(a)
+    L.check(L.lib().gmp_mse_sum_bwd(_ptr(a), _ptr(b), _ptr(g_scale), _ptr(ga), a.numel(), _stream(a)), "gmp_mse_sum_bwd")
+    return ga
+
+
+def sigmoid_fwd(x: Tensor) -> Tensor:
+    _need(x, torch.float32, "x")
+    y = torch.empty_like(x)
+    L.check(L.lib().gmp_sigmoid_fwd(_ptr(x), _ptr(y), x.numel(), _stream(x)), "gmp_sigmoid_fwd")
+    return y
+
+
+def sigmoid_bwd(g: Tensor, y: Tensor) -> Tensor:
+    _need(g, torch.float32, "g")
+    out = torch.empty_like(y)
+    L.check(L.lib().gmp_sigmoid_bwd(_ptr(g), _ptr(y), _ptr(out), y.numel(), _stream(y)), "gmp_sigmoid_bwd")
+    return out
+
+
+def bce_sum_fwd(p: Tensor, labels: Tensor) -> Tensor:
+    _need(p, torch.float32, "p"); _need(labels, torch.float32, "labels")
+    if p.shape != labels.shape:
+        raise L.GnnmpError("bce_sum: shapes differ")
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    ws = _loss_ws(p.numel(), p.device)
+    L.check(L.lib().gmp_bce_sum_fwd(_ptr(p), _ptr(labels), p.numel(), _ptr(loss), _ptr(ws), ws.numel(), _stream(p)), "gmp_bce_sum_fwd")
+    return loss
+
+
+def bce_sum_bwd(p: Tensor, labels: Tensor, g_scale: Tensor) -> Tensor:
+    gp = torch.empty_like(p)
+    L.check(L.lib().gmp_bce_sum_bwd(_ptr(p), _ptr(labels), _ptr(g_scale), _ptr(gp), p.numel(), _stream(p)), "gmp_bce_sum_bwd")
+    return gp
+
+
+def cross_entropy_sum_fwd(logits: Tensor, target: Tensor) -> Tensor:
+    _need(logits, torch.float32, "logits", 2); _need(target, torch.int64, "target", 1)
+    if target.numel() != logits.size(0):
+        raise L.GnnmpError("cross_entropy: target length")
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = _loss_ws(logits.size(0), logits.device)
+    L.check(L.lib().gmp_cross_entropy_sum_fwd(_ptr(logits), _ptr(target), logits.size(0), logits.size(1), _ptr(loss),
+                                              _ptr(ws), ws.numel(), _stream(logits)), "gmp_cross_entropy_sum_fwd")
+    return loss
+
+
+def cross_entropy_sum_bwd(logits: Tensor, target: Tensor, g_scale: Tensor) -> Tensor:
+    gl = torch.empty_like(logits)
+    L.check(L.lib().gmp_cross_entropy_sum_bwd(_ptr(logits), _ptr(target), logits.size(0), logits.size(1), _ptr(g_scale),
+                                              _ptr(gl), _stream(logits)), "gmp_cross_entropy_sum_bwd")
+    return gl
+
+
+def row_fill_(dst: Tensor, idx: Tensor, src: Tensor, broadcast: bool) -> Tensor:
+    F = _feat_ok(dst, "dst")
+    _need(idx, torch.int64, "idx", 1); _need(src, torch.float32, "src")
+    if broadcast:
+        if src.numel() != F:
+            raise L.GnnmpError("row_fill: broadcast source must have F elements")
+    elif tuple(src.shape) != (idx.numel(), F):
+        raise L.GnnmpError("row_fill: source shape")
+    L.check(L.lib().gmp_row_fill(_ptr(dst), _ptr(idx), _ptr(src), idx.numel(), dst.size(0), F, int(broadcast), _stream(dst)),
+            "gmp_row_fill")
+    return dst

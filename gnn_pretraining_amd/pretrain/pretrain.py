@@ -1,0 +1,190 @@
+"""Pre-training driver: same scheme tables, step ordering and CLI as src/pretrain/pretrain.py
+(``--exp_name S --seed N``), running on libgnnmp with synthetic batches (the TUDataset downloads
+of the reference need the network).  wandb is replaced by a JSONL logger with the same metric keys.
+
+Build-only flags (the reference's flags are unchanged): --epochs, --steps-per-epoch, --log, --device.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+
+from ..constants import PRETRAIN_TUDATASETS
+from ..models.pretrain_model import PretrainableGNN
+from .. import synthetic
+from .control import AdaptiveLossBalancer, GradientSurgery, GRLScheduler, TaskSpecificOptimizer, TemperatureScheduler
+from .tasks import BasePretrainTask, instantiate_tasks
+
+BATCH_SIZE = 32
+EPOCHS = 50
+MAX_GRAD_NORM = 0.5
+PATIENCE_FRACTION = 0.5
+
+PRETRAIN_DOMAINS = {k: (["ENZYMES"] if k == "b4" else PRETRAIN_TUDATASETS) for k in ("b2", "b3", "b4", "s1", "s2", "s3", "s4", "s5")}
+_ALL5 = ["node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop"]
+ACTIVE_TASKS = {
+    "b2": ["node_feat_mask"], "b3": ["node_contrast"], "b4": list(_ALL5),
+    "s1": ["node_feat_mask", "link_pred"], "s2": ["node_contrast", "graph_contrast"],
+    "s3": _ALL5[:4], "s4": list(_ALL5), "s5": _ALL5 + ["domain_adv"],
+}
+OUTPUT_DIR = Path(__file__).resolve().parents[2] / "outputs" / "pretrain"
+
+
+@dataclass
+class PretrainConfig:
+    exp_name: str
+    seed: int
+    pretrain_domains: List[str] = field(default=None)
+    active_tasks: List[str] = field(default=None)
+
+    def __post_init__(self) -> None:
+        self.pretrain_domains = PRETRAIN_DOMAINS[self.exp_name]
+        self.active_tasks = ACTIVE_TASKS[self.exp_name]
+
+
+def set_global_seed(seed: int) -> None:
+    torch.manual_seed(seed)
+
+
+class StepState:
+    """Everything one optimisation step touches besides the model."""
+
+    def __init__(self, model: PretrainableGNN, cfg: PretrainConfig, steps_per_epoch: int, epochs: int = EPOCHS) -> None:
+        self.model, self.cfg = model, cfg
+        self.grl = GRLScheduler(total_epochs=epochs, steps_per_epoch=steps_per_epoch)
+        self.temperature = TemperatureScheduler(total_steps=steps_per_epoch * epochs)
+        self.tasks: Dict[str, BasePretrainTask] = instantiate_tasks(model, cfg.active_tasks, self.grl, self.temperature)
+        self.optimizer = TaskSpecificOptimizer(model=model, active_tasks=cfg.active_tasks)
+        self.surgery = GradientSurgery(device=model.device)
+        self.balancer = AdaptiveLossBalancer()
+
+
+def train_step(state: StepState, domain_batches, generator: torch.Generator, artefacts: Optional[Dict] = None,
+               order: Optional[List[str]] = None):
+    """One iteration of run_training (pretrain.py:113-155) without the logging: task losses in
+    ACTIVE_TASKS order, balancer, PCGrad (or a plain backward for one task), clip 0.5, AdamW, schedulers.
+    `artefacts[task]` / `order` inject the RNG-dependent pieces for parity runs."""
+    model = state.model
+    per_task, per_domain = {}, {}
+    for name, task in state.tasks.items():
+        art = artefacts[name] if artefacts is not None and name in artefacts else task.draw(domain_batches, generator)
+        per_task[name], per_domain[name] = task.loss(domain_batches, art)
+    lam = state.grl()
+    main = {k: v for k, v in per_task.items() if k != "domain_adv"}
+    total = state.balancer.balance_losses(main, lam)
+    state.optimizer.zero_grad(set_to_none=True)
+    metrics = state.surgery.apply_gradient_surgery(model, main, list(main.keys()), order=order)
+    if not metrics:
+        total.backward(retain_graph="domain_adv" in per_task)
+    if "domain_adv" in per_task:
+        per_task["domain_adv"].backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=MAX_GRAD_NORM)
+    state.optimizer.step()
+    state.grl.step()
+    state.temperature.step()
+    return per_task, per_domain, total, metrics
+
+
+class JsonlLogger:
+    """Stand-in for wandb.log with the reference's keys (pretrain.py:157-190)."""
+
+    def __init__(self, path: Optional[str]) -> None:
+        self.f = open(path, "a") if path else None
+
+    def log(self, metrics: Dict, step: int) -> None:
+        if self.f:
+            self.f.write(json.dumps({"step": step, **metrics}) + "\n")
+            self.f.flush()
+
+
+def run_training(state: StepState, steps: int, generator: torch.Generator, device, epoch: int, global_step: List[int],
+                 logger: JsonlLogger) -> None:
+    state.model.train()
+    for _ in range(steps):
+        global_step[0] += 1
+        batches = {d: b.to(device) for d, b in synthetic.pretrain_step_batches(generator, state.cfg.pretrain_domains).items()}
+        per_task, per_domain, total, gs = train_step(state, batches, generator)
+        m = {f"train/loss/{t}": float(v.detach()) for t, v in per_task.items()}
+        for t, dd in per_domain.items():
+            for d, v in dd.items():
+                m[f"train/loss/{d}/{t}"] = float(v.detach())
+        m["train/loss/total"] = float(total.detach())
+        m["train/progress/epoch"] = epoch
+        for t, w in state.balancer.get_current_weights().items():
+            m[f"train/loss_balancer/weight/{t}"] = w
+        m.update(gs)
+        logger.log(m, global_step[0])
+
+
+@torch.no_grad()
+def run_evaluation(state: StepState, generator: torch.Generator, device, val_steps: int = 2) -> float:
+    """pretrain.py:193-281 on synthetic validation batches: every task x every domain, eval mode, the shared
+    generator advances (the reference's evaluation is stochastic too)."""
+    state.model.eval()
+    per_task = {}
+    for name, task in state.tasks.items():
+        dom = []
+        for d in state.cfg.pretrain_domains:
+            losses = []
+            for _ in range(val_steps):
+                b = synthetic.pretrain_step_batches(generator, [d], graphs_per_domain=BATCH_SIZE)[d].to(device)
+                losses.append(task.compute_loss({d: b}, generator)[0])
+            dom.append(torch.stack(losses).mean())
+        per_task[name] = torch.stack(dom).mean()
+    main = {k: v for k, v in per_task.items() if k != "domain_adv"}
+    return float(state.balancer.balance_losses(main, state.grl()))
+
+
+def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: int = 462, log_path: Optional[str] = None,
+             device: Optional[str] = None) -> Path:
+    set_global_seed(cfg.seed)
+    generator = torch.Generator()
+    generator.manual_seed(cfg.seed)
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP path needs a GPU (no CPU fallback); the CPU oracle lives under oracle/")
+        device = "cuda"
+    dev = torch.device(device)
+    OUTPUT_DIR.mkdir(parents=True, exist_ok=True)
+    model = PretrainableGNN(device=dev, domain_names=cfg.pretrain_domains, task_names=cfg.active_tasks)
+    state = StepState(model, cfg, steps_per_epoch, epochs)
+    logger = JsonlLogger(log_path)
+    best, stale, global_step = float("inf"), 0, [0]
+    path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"
+    for epoch in range(1, epochs + 1):
+        t0 = time.time()
+        run_training(state, steps_per_epoch, generator, dev, epoch, global_step, logger)
+        val = run_evaluation(state, generator, dev)
+        logger.log({"val/loss/total": val, "epoch_seconds": time.time() - t0}, global_step[0])
+        if val < best:
+            best, stale = val, 0
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "val_metrics": {"val/loss/total": val}}, path)
+        else:
+            stale += 1
+        if stale >= int(epochs * PATIENCE_FRACTION):
+            break
+    return path
+
+
+def main() -> None:
+    p = argparse.ArgumentParser()
+    p.add_argument("--exp_name", type=str, required=True)
+    p.add_argument("--seed", type=int, required=True)
+    p.add_argument("--epochs", type=int, default=EPOCHS)
+    p.add_argument("--steps-per-epoch", type=int, default=462)
+    p.add_argument("--log", type=str, default=None)
+    p.add_argument("--device", type=str, default=None)
+    a = p.parse_args()
+    path = pretrain(PretrainConfig(exp_name=a.exp_name, seed=a.seed), a.epochs, a.steps_per_epoch, a.log, a.device)
+    print(f"saved {path}")
+
+
+if __name__ == "__main__":
+    main()

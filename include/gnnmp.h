@@ -92,7 +92,8 @@ int gmp_row_gather(const float* src, const int64_t* idx, const int32_t* seg_ptr,
 /* ------------------------------------------------------------------------- *
  * global_max_pool (tasks.py:242,245): out[b,f] = max over rows ptr[b]..ptr[b+1];
  * empty segment -> 0 (PyG: new_zeros + scatter_reduce amax, include_self=False).
- * bwd splits g evenly between tied maxima, as torch's scatter_reduce('amax') does.
+ * bwd splits g evenly between tied maxima, as torch's scatter_reduce('amax') does
+ * (including its count of the zero-initialised output as one more tie when max == 0).
  * ------------------------------------------------------------------------- */
 int gmp_segment_max_fwd(const float* x, const int32_t* ptr, float* out, int64_t num_segments, int feat,
                         gmp_stream_t stream);
@@ -193,6 +194,46 @@ int gmp_nt_xent_fwd(const float* z1, const float* z2, int64_t n, int dim, float 
 int gmp_nt_xent_bwd(const float* z1, const float* z2, int64_t n, int dim, float temperature,
                     const float* g_scale, float* g_z1, float* g_z2,
                     void* workspace /* the one fwd filled */, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * MLPHead pieces (heads.py:42-45): Linear -> ReLU -> Dropout.  The ReLU rides in the
+ * GEMM epilogue; these two handle the dropout and the fused backward
+ *   out = g * dropmask * (act > 0),  act = the ReLU output.  numel % 4 == 0.
+ * ------------------------------------------------------------------------- */
+int gmp_dropout_fwd(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint32_t stream_id,
+                    gmp_stream_t stream);
+int gmp_relu_dropout_bwd(const float* g, const float* act, float* out, int64_t numel, float p, uint64_t seed,
+                         uint32_t stream_id, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Task losses (sum reductions; the caller divides by the pooled size, tasks.py:84-93).
+ *   mse_sum          F.mse_loss(a, b, reduction='sum')               tasks.py:83,305
+ *   sigmoid          torch.sigmoid of the edge scores                heads.py:67
+ *   bce_sum          F.binary_cross_entropy(p, y, 'sum'), log terms clamped at -100,
+ *                    backward g*(p-y)/max(p(1-p),1e-12) as torch does  tasks.py:120
+ *   cross_entropy_sum F.cross_entropy(logits, target, 'sum')         tasks.py:336, finetune.py:158,177
+ *   *_bwd take the upstream scalar gradient as device float[1] g_scale.
+ *   workspace >= gmp_loss_workspace_bytes(numel or rows).
+ * gmp_row_fill: dst[idx[m],:] = broadcast ? src[0,:] : src[m,:]  (mask-token rows,
+ *   pretrain_model.py:82-85); out-of-range idx entries are skipped.
+ * ------------------------------------------------------------------------- */
+size_t gmp_loss_workspace_bytes(int64_t numel);
+int gmp_mse_sum_fwd(const float* a, const float* b, int64_t numel, float* loss, void* workspace,
+                    size_t workspace_bytes, gmp_stream_t stream);
+int gmp_mse_sum_bwd(const float* a, const float* b, const float* g_scale, float* g_a, int64_t numel,
+                    gmp_stream_t stream);
+int gmp_sigmoid_fwd(const float* x, float* y, int64_t numel, gmp_stream_t stream);
+int gmp_sigmoid_bwd(const float* g, const float* y, float* out, int64_t numel, gmp_stream_t stream);
+int gmp_bce_sum_fwd(const float* p, const float* labels, int64_t numel, float* loss, void* workspace,
+                    size_t workspace_bytes, gmp_stream_t stream);
+int gmp_bce_sum_bwd(const float* p, const float* labels, const float* g_scale, float* g_p, int64_t numel,
+                    gmp_stream_t stream);
+int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t rows, int classes,
+                              float* loss, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+int gmp_cross_entropy_sum_bwd(const float* logits, const int64_t* target, int64_t rows, int classes,
+                              const float* g_scale, float* g_logits, gmp_stream_t stream);
+int gmp_row_fill(float* dst, const int64_t* idx, const float* src, int64_t num_idx, int64_t num_dst_rows,
+                 int feat, int broadcast, gmp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -174,7 +174,9 @@ def global_max_pool(x: Tensor, batch: Tensor, size: Optional[int] = None) -> Ten
     """PyG scatter(reduce='max') on the CPU path: ``new_zeros(size).scatter_reduce_
     (0, index, src, 'amax', include_self=False)``.  Its autograd splits the
     incoming gradient EVENLY between tied maxima (torch derivative of
-    scatter_reduce amax) -- that is the tie rule the HIP kernel reproduces."""
+    scatter_reduce amax) -- that is the tie rule the HIP kernel reproduces.  Measured
+    here (torch 2.10): the zero-initialised output counts as one more tie whenever
+    the segment maximum is exactly 0, even with include_self=False."""
     B = int(batch.max()) + 1 if size is None else size
     idx = batch.view(-1, 1).expand_as(x)
     return x.new_zeros(B, x.size(1)).scatter_reduce(0, idx, x, reduce="amax", include_self=False)

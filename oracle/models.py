@@ -73,10 +73,11 @@ class GINLayer(nn.Module):
             nn.Linear(HIDDEN, 2 * HIDDEN), nn.BatchNorm1d(2 * HIDDEN), nn.ReLU(),
             nn.Linear(2 * HIDDEN, HIDDEN)))
         self.batch_norm = nn.BatchNorm1d(HIDDEN)
+        self.dropout_p = DROPOUT        # plain attribute so parity tests can switch dropout off under train-mode BN
 
     def forward(self, h: Tensor, edge_index: Tensor) -> Tensor:
         u = self.gin_conv(h, edge_index) + h
-        return F.dropout(F.relu(self.batch_norm(u)), p=DROPOUT, training=self.training)
+        return F.dropout(F.relu(self.batch_norm(u)), p=self.dropout_p, training=self.training)
 
 
 class GINBackbone(nn.Module):
