@@ -113,6 +113,21 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
     }
 }
 
+// any feature width: one thread per output element (class logits, 12 graph properties ...)
+__global__ __launch_bounds__(BLOCK) void seg_sum_scalar_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
+                                                               const int* __restrict__ idx, float* __restrict__ out,
+                                                               int64_t nrows, int F, int mean, int accumulate) {
+    const int64_t total = nrows * F;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = i / F;
+        const int f = (int)(i % F), s = ptr[r], e = ptr[r + 1];
+        float acc = 0.f;
+        for (int k = s; k < e; ++k) acc += src[(int64_t)(idx ? idx[k] : k) * F + f];
+        if (mean) acc /= (float)(e - s > 1 ? e - s : 1);
+        out[i] = accumulate ? out[i] + acc : acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ p, int n, float* out) {
     __shared__ float sh[256];
     float s = 0.f;
@@ -213,9 +228,15 @@ extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t
 
 extern "C" int gmp_segment_sum(const float* src, const int32_t* ptr, const int32_t* idx, float* out, int64_t nseg,
                                int feat, int mean, int accumulate, gmp_stream_t stream) {
-    if (int rc = check_feat("segment_sum", feat)) return rc;
     if (nseg < 0 || (nseg > 0 && (!src || !ptr || !out))) return gmp::fail(GMP_ERR_ARG, "segment_sum: null pointer");
     if (nseg == 0) return GMP_OK;
+    if (feat > 0 && feat % 4) {
+        int64_t b = (nseg * feat + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(seg_sum_scalar_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(BLOCK), 0, (hipStream_t)stream, src, ptr,
+                           idx, out, nseg, feat, mean, accumulate);
+        return gmp::check_launch("seg_sum_scalar_kernel");
+    }
+    if (int rc = check_feat("segment_sum", feat)) return rc;
     const int F4 = feat / 4, nv = (F4 + 63) / 64;
     Plan p = make_plan(nseg);
     hipStream_t st = (hipStream_t)stream;

@@ -30,6 +30,25 @@ __global__ __launch_bounds__(BLOCK) void row_gather_kernel(const float4* __restr
     }
 }
 
+// any feature width (e.g. 7 class logits): one thread per element
+__global__ __launch_bounds__(BLOCK) void row_gather_scalar_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                                  const int* __restrict__ seg_ptr, float* __restrict__ out,
+                                                                  int64_t M, int64_t nsrc, int F) {
+    const int64_t total = M * F;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t m = i / F, r = idx[m];
+        float v = 0.f;
+        if (r >= 0 && r < nsrc) {
+            v = src[r * F + i % F];
+            if (seg_ptr) {
+                int c = seg_ptr[r + 1] - seg_ptr[r];
+                v /= (float)(c > 1 ? c : 1);
+            }
+        }
+        out[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __restrict__ x, const int* __restrict__ ptr,
                                                             float4* __restrict__ out, int64_t B, int F4) {
     const int lane = threadIdx.x % GMP_WAVE;
@@ -131,9 +150,15 @@ int feat_ok(const char* who, int feat) {
 
 extern "C" int gmp_row_gather(const float* src, const int64_t* idx, const int32_t* seg_ptr, float* out, int64_t M,
                               int64_t num_src_rows, int feat, gmp_stream_t stream) {
-    if (int rc = feat_ok("row_gather", feat)) return rc;
+    if (feat <= 0) return gmp::fail(GMP_ERR_ARG, "row_gather: feature width %d", feat);
     if (M < 0 || num_src_rows < 0 || (M > 0 && (!src || !idx || !out))) return gmp::fail(GMP_ERR_ARG, "row_gather: bad argument");
     if (M == 0) return GMP_OK;
+    if (feat % 4) {
+        int64_t b = (M * feat + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(row_gather_scalar_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(BLOCK), 0, (hipStream_t)stream, src,
+                           idx, seg_ptr, out, M, num_src_rows, feat);
+        return gmp::check_launch("row_gather_scalar_kernel");
+    }
     hipLaunchKernelGGL(row_gather_kernel, dim3(grid_for(M)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)src, idx,
                        seg_ptr, (float4*)out, M, num_src_rows, feat / 4);
     return gmp::check_launch("row_gather_kernel");

@@ -107,7 +107,8 @@ def gin_aggregate_bwd(g_out: Tensor, rowptr_t: Tensor, col_t: Tensor, eps: Tenso
 
 def segment_sum(src: Tensor, ptr: Tensor, idx: Optional[Tensor], mean: bool = False,
                 out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
-    F = _feat_ok(src, "src")
+    _need(src, torch.float32, "src", 2)
+    F = src.size(1)
     _need(ptr, torch.int32, "ptr", 1)
     if idx is not None:
         _need(idx, torch.int32, "idx", 1)
@@ -121,7 +122,8 @@ def segment_sum(src: Tensor, ptr: Tensor, idx: Optional[Tensor], mean: bool = Fa
 
 
 def row_gather(src: Tensor, idx: Tensor, seg_ptr: Optional[Tensor] = None) -> Tensor:
-    F = _feat_ok(src, "src")
+    _need(src, torch.float32, "src", 2)
+    F = src.size(1)
     _need(idx, torch.int64, "idx", 1)
     if seg_ptr is not None:
         _need(seg_ptr, torch.int32, "seg_ptr", 1)

@@ -27,10 +27,35 @@ def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
     return (got - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
 
 
-def assert_close(got, want, rtol, what=""):
-    e = rel_err(got, want)
+def assert_close(got, want, rtol, what="", floor=0.0):
+    """max |got - want| <= rtol * max(max|want|, floor).  `floor` guards tensors that are analytically
+    zero (e.g. the gradient of a bias that feeds a train-mode BatchNorm): both sides hold rounding noise."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    e = (got - want).abs().max().item() / max(want.abs().max().item(), floor, 1e-30)
     assert e <= rtol, f"{what}: max rel err {e:.3e} > {rtol}"
 
 
 def copy_state(dst: nn.Module, src: nn.Module) -> None:
     dst.load_state_dict({k: v.detach().cpu().clone() for k, v in src.state_dict().items()})
+
+
+def assert_grad_close(got, want, gmax, what=""):
+    """Gradient parity through ReLU networks.  An fp32 pre-activation within rounding of 0 gates its ReLU
+    differently in two correct implementations (about one such element per backbone forward at these
+    sizes: 1e6 pre-activations x density(0) x 2e-6); the gradient of the graph containing it then moves
+    by ~1e-3.  scripts/diag_precision.py shows both implementations otherwise sit 2-7e-7 from fp64.
+    scripts/diag_tasks_fp64.py shows the error is bimodal -- ~1e-6 without a flip, ~1e-3 with one -- and
+    that the fp32 ORACLE shows the same flips against its own fp64 run (up to 1e-1 on a scalar eps
+    gradient).  So: max-norm within 3e-2, L2 within 1e-2, measured against max(|want|, 1e-3 * largest
+    gradient) (the floor covers analytically-zero gradients such as a bias feeding a train-mode BatchNorm).
+    Flip-free gradient checks at 1e-4 .. 2e-4 are the per-operator tests in test_gpu_ops.py."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    d = got - want
+    # a scalar gradient (GINConv.eps) is one cancelling sum of N*256 products: its own magnitude says nothing
+    # about the size of the terms, so it is held against the largest gradient instead
+    floor = gmax if want.numel() == 1 else 1e-3 * gmax
+    e_max = d.abs().max().item() / max(want.abs().max().item(), floor, 1e-30)
+    e_l2 = d.norm().item() / max(want.norm().item(), floor * want.numel() ** 0.5, 1e-30)
+    assert e_max <= 3e-2 and e_l2 <= 1e-2, f"{what}: max-norm rel {e_max:.3e}, L2 rel {e_l2:.3e}"
