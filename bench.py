@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Headline benchmark: s4 multi-task pre-training steps on synthetic ENZYMES-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one full optimisation step of scheme s4 (5 task losses over 4 domains x 8 graphs,
+5 per-task backwards, PCGrad, clip 0.5, AdamW) == run_training's loop body
+(reference src/pretrain/pretrain.py:113-155).  Prints ONE JSON line (rank 0) with
+  value      graphs/s over all ranks (weak scaling: every rank runs its own 32-graph step),
+  roofline   the GIN aggregation kernel on the 65,536-graph rung (x = 2.2 GB, streams from HBM),
+             algorithmic bytes / live HIP-event time, against the 8 TB/s HBM3E peak,
+  cpu_baseline  the CPU oracle's s4 step on this box's host cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from gnn_pretraining_amd import dist as D, ops, synthetic as S  # noqa: E402
+from gnn_pretraining_amd.graph import Batch  # noqa: E402
+from gnn_pretraining_amd.models import PretrainableGNN  # noqa: E402
+from gnn_pretraining_amd.pretrain import pretrain as PT  # noqa: E402
+
+SCHEME = "s4"
+GRAPHS_PER_STEP = 32
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
+
+
+def make_pool(seed: int, device):
+    gen = torch.Generator().manual_seed(seed)
+    domains = PT.PRETRAIN_DOMAINS[SCHEME]
+    pool = []
+    for _ in range(POOL):
+        host = S.pretrain_step_batches(gen, domains, enzymes_shaped=True)
+        pool.append({d: b.to(device) for d, b in host.items()})
+    return pool
+
+
+def run_steps(state, pool, gen, n, start=0):
+    for i in range(n):
+        PT.train_step(state, pool[(start + i) % len(pool)], gen)
+
+
+def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iters: int = 20):
+    """Time gmp_gin_aggregate_fwd alone on the 65,536-graph rung."""
+    gen = torch.Generator().manual_seed(7)
+    base = Batch.from_data_list([S.random_graph(gen, 4) for _ in range(distinct)])
+    reps = graphs // distinct
+    n0, e0 = base.num_nodes, base.num_edges
+    N, E = n0 * reps, e0 * reps
+    ei = base.edge_index.to(device)
+    offs = (torch.arange(reps, device=device) * n0).view(1, reps, 1)
+    ei_big = (ei.view(2, 1, e0) + offs).reshape(2, E).contiguous()       # the 1,024 graphs tiled 64x
+    csr = ops.csr_build(ei_big, N)
+    del ei_big
+    x = torch.randn(N, 256, device=device)
+    eps = torch.zeros(1, device=device)
+    out = torch.empty_like(x)
+    l = ops.L.lib()
+    args = (ops._ptr(x), ops._ptr(csr.rowptr), ops._ptr(csr.col), ops._ptr(eps), ops._ptr(out), N, 256)
+    for _ in range(3):
+        ops.L.check(l.gmp_gin_aggregate_fwd(*args, ops._stream(x)), "aggregate")
+    torch.cuda.synchronize(device)
+    # HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        ops.L.check(l.gmp_gin_aggregate_fwd(*args, ops._stream(x)), "aggregate")
+        ev[i + 1].record()
+    torch.cuda.synchronize(device)
+    ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(iters)) / iters
+    alg_bytes = 2 * 4 * 256 * N + 4 * (N + 1) + 4 * E
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "seg_sum_kernel<1,SELF,IDX> (gmp_gin_aggregate_fwd)",
+            "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters}
+
+
+def cpu_baseline(seed: int, budget_s: float = 20.0):
+    """The CPU oracle (a port: the reference itself needs torch_geometric) on this box's host cores."""
+    from oracle import models as OM, tasks as OTk, train as OTr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_util import to_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed)
+    domains, tasks = PT.PRETRAIN_DOMAINS[SCHEME], PT.ACTIVE_TASKS[SCHEME]
+    model = OM.PretrainableGNN(torch.device("cpu"), domains, tasks)
+    model.train()
+    temp, grl = OTr.TemperatureScheduler(462 * 50), OTr.GRLScheduler(50, 462)
+    otasks = OTk.instantiate_tasks(model, tasks, grl, temp)
+    opt, bal = OTr.make_optimizer(model, tasks), OTr.AdaptiveLossBalancer()
+    pool = [{d: to_oracle(b) for d, b in S.pretrain_step_batches(gen, domains).items()} for _ in range(4)]
+    for i in range(2):
+        OTr.train_step(model, otasks, opt, bal, grl, temp, pool[i % 4], gen)
+    times, t_end = [], time.time() + budget_s
+    while time.time() < t_end and len(times) < 50:
+        t0 = time.time()
+        OTr.train_step(model, otasks, opt, bal, grl, temp, pool[len(times) % 4], gen)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(GRAPHS_PER_STEP / med, 2), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} s4 steps of 32 synthetic ENZYMES-shaped graphs (median {med * 1e3:.1f} ms/step), "
+                      f"torch-only oracle, torch.set_num_threads({cores})"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = D.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    rank = D.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    seed = 42
+    torch.manual_seed(seed)                        # identical replicas on every rank
+    model = PretrainableGNN(device, PT.PRETRAIN_DOMAINS[SCHEME], PT.ACTIVE_TASKS[SCHEME])
+    model.train()
+    sync = D.FlatGradSync() if world > 1 else None
+    state = PT.StepState(model, PT.PretrainConfig(SCHEME, seed), steps_per_epoch=462, grad_sync=sync,
+                         shuffle_rng=random.Random(seed))
+    pool = make_pool(seed + 1000 * rank, device)   # every rank draws its own batches (weak scaling)
+    gen = torch.Generator().manual_seed(seed + rank)
+
+    run_steps(state, pool, gen, a.warmup)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run_steps(state, pool, gen, a.steps, start=a.warmup)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = cpu = None
+    if rank == 0 and not a.no_roofline:
+        roof = aggregation_roofline(device)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(seed)
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        line = {
+            "metric": "pretrain graphs/sec (s4 multi-task)", "value": round(GRAPHS_PER_STEP * world * a.steps / elapsed, 2),
+            "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
+                                   "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
+                       "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

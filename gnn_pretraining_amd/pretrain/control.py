@@ -89,8 +89,10 @@ class GradientSurgery:
     (gradient_surgery.py:61): only tensors present in the FIRST shuffled task's gradient set
     receive the PCGrad mean; the others keep whatever the LAST task's backward left in .grad."""
 
-    def __init__(self, device: torch.device) -> None:
+    def __init__(self, device: torch.device, grad_sync=None, shuffle_rng: Optional[random.Random] = None) -> None:
         self.device = device
+        self.grad_sync = grad_sync          # dist.FlatGradSync: per-task gradients are averaged over ranks BEFORE PCGrad
+        self.shuffle_rng = shuffle_rng      # data-parallel runs need the same task order on every rank
 
     def apply_gradient_surgery(self, model: nn.Module, task_losses: Dict[str, Tensor], task_names: List[str],
                                order: Optional[List[str]] = None) -> Dict[str, float]:
@@ -102,9 +104,14 @@ class GradientSurgery:
             model.zero_grad(set_to_none=True)
             loss.backward(retain_graph=True)
             grads[t] = {n: p.grad for n, p in named if p.grad is not None}      # fresh tensors: no clone needed
+        if self.grad_sync is not None:
+            self.grad_sync.average_task_grads_(grads)
         if order is None:
             order = list(task_names)
-            random.shuffle(order)                       # unseeded global RNG, as in the reference (:43)
+            if self.shuffle_rng is not None:
+                self.shuffle_rng.shuffle(order)
+            else:
+                random.shuffle(order)                   # unseeded global RNG, as in the reference (:43)
         final, metrics = self._pcgrad(grads, order)
         for n, p in named:
             if n in final:

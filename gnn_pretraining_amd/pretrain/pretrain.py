@@ -56,13 +56,14 @@ def set_global_seed(seed: int) -> None:
 class StepState:
     """Everything one optimisation step touches besides the model."""
 
-    def __init__(self, model: PretrainableGNN, cfg: PretrainConfig, steps_per_epoch: int, epochs: int = EPOCHS) -> None:
-        self.model, self.cfg = model, cfg
+    def __init__(self, model: PretrainableGNN, cfg: PretrainConfig, steps_per_epoch: int, epochs: int = EPOCHS,
+                 grad_sync=None, shuffle_rng=None) -> None:
+        self.model, self.cfg, self.grad_sync = model, cfg, grad_sync
         self.grl = GRLScheduler(total_epochs=epochs, steps_per_epoch=steps_per_epoch)
         self.temperature = TemperatureScheduler(total_steps=steps_per_epoch * epochs)
         self.tasks: Dict[str, BasePretrainTask] = instantiate_tasks(model, cfg.active_tasks, self.grl, self.temperature)
         self.optimizer = TaskSpecificOptimizer(model=model, active_tasks=cfg.active_tasks)
-        self.surgery = GradientSurgery(device=model.device)
+        self.surgery = GradientSurgery(device=model.device, grad_sync=grad_sync, shuffle_rng=shuffle_rng)
         self.balancer = AdaptiveLossBalancer()
 
 
@@ -85,6 +86,8 @@ def train_step(state: StepState, domain_batches, generator: torch.Generator, art
         total.backward(retain_graph="domain_adv" in per_task)
     if "domain_adv" in per_task:
         per_task["domain_adv"].backward()
+    if state.grad_sync is not None and (not metrics or "domain_adv" in per_task):
+        state.grad_sync.average_model_grads_(model)      # single-task schemes / the adversarial term: plain DP mean
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=MAX_GRAD_NORM)
     state.optimizer.step()
     state.grl.step()
