@@ -36,6 +36,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
 
 
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """Cores this process may actually use (the GPU box gives one GPU's job a 16-core share of a big host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:                                        # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GMP_BENCH_MAX_CORES", "16"))))
+
+
 def make_pool(seed: int, device):
     gen = torch.Generator().manual_seed(seed)
     domains = PT.PRETRAIN_DOMAINS[SCHEME]
@@ -91,7 +110,7 @@ def cpu_baseline(seed: int, budget_s: float = 20.0):
     from oracle import models as OM, tasks as OTk, train as OTr
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from parity_util import to_oracle
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
@@ -143,7 +162,9 @@ def main() -> None:
     pool = make_pool(seed + 1000 * rank, device)   # every rank draws its own batches (weak scaling)
     gen = torch.Generator().manual_seed(seed + rank)
 
+    log(f"rank {rank}/{world}: model + {POOL} step inputs resident, warming up {a.warmup} steps")
     run_steps(state, pool, gen, a.warmup)
+    log("timing")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
@@ -158,10 +179,13 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log(f"{a.steps} steps in {elapsed:.3f} s")
     roof = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)
+        log(f"roofline {roof['achieved']} GB/s")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline ...")
         cpu = cpu_baseline(seed)
     if rank == 0:
         ms = elapsed / a.steps * 1e3

@@ -24,14 +24,16 @@ __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
 }
 __device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// NV = float4 per lane (F <= 256*NV).  SELF: out = scale*self + sum.  DOT: also
-// accumulate <self[r], dotx[r]> per block into dot_partials[blockIdx] (eps gradient).
-template <int NV, bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT>
+// NV = float4 per lane (F <= 256*NV).  SELF: out = scale*self + sum.  DOT: also write
+// rowdot[r] = <self[r], dotx[r]> (eps gradient, reduced per task afterwards).  ADDEND: out += addend[r]
+// (the residual branch's gradient joins the aggregation's in the same pass).
+template <int NV, bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT, bool ADDEND = false>
 __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict__ src, const int* __restrict__ ptr,
                                                         const int* __restrict__ idx, const float4* __restrict__ self,
                                                         const float* __restrict__ eps, const float4* __restrict__ dotx,
-                                                        float4* __restrict__ out, float* __restrict__ dot_partials,
-                                                        int64_t nrows, int F4, int rows_per_wave) {
+                                                        float4* __restrict__ out, float* __restrict__ rowdot,
+                                                        int64_t nrows, int F4, int rows_per_wave,
+                                                        const float4* __restrict__ addend = nullptr) {
     // XCD-aware: hardware deals blocks round-robin over 8 XCDs; give XCD k the k-th
     // contiguous eighth of the chunk space (gridDim.x is a multiple of 8).
     const int per_xcd = gridDim.x / NUM_XCD;
@@ -42,7 +44,6 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
     int64_t r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
     float scale = 1.f;
     if (SELF) scale = 1.f + (eps ? eps[0] : 0.f);
-    float dot = 0.f;
     bool act[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) act[v] = lane + v * GMP_WAVE < F4;
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
         const int start = __builtin_amdgcn_readfirstlane(ptr[r]);
         const int end = __builtin_amdgcn_readfirstlane(ptr[r + 1]);
         float4 acc[NV];
+        float dot = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (SELF) {
@@ -96,19 +98,13 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
                 float4 a = acc[v];
                 if (MEAN) a = make_float4(a.x * m, a.y * m, a.z * m, a.w * m);
                 const int64_t o = r * F4 + lane + v * GMP_WAVE;
+                if (ADDEND) a = f4add(a, addend[o]);
                 if (ACCUM) a = f4add(out[o], a);
                 out[o] = a;
             }
-    }
-    if (DOT) {
-        __shared__ float wsum[WAVES_PER_BLOCK];
-        dot = gmp::wave_sum(dot);
-        if (lane == 0) wsum[wv] = dot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float s = 0.f;
-            for (int i = 0; i < WAVES_PER_BLOCK; ++i) s += wsum[i];
-            dot_partials[lb] = s;   // logical block id: fixed summation order in the final pass
+        if (DOT) {
+            dot = gmp::wave_sum(dot);
+            if (lane == 0) rowdot[r] = dot;
         }
     }
 }
@@ -158,14 +154,14 @@ Plan make_plan(int64_t nrows) {
     return Plan{(int)blocks, (int)rpw};
 }
 
-template <bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT>
+template <bool SELF, bool IDX, bool MEAN, bool ACCUM, bool DOT, bool ADDEND = false>
 int launch_nv(int nv, const Plan& p, hipStream_t st, const float* src, const int* ptr, const int* idx,
               const float* self, const float* eps, const float* dotx, float* out, float* partials, int64_t nrows,
-              int F4) {
+              int F4, const float* addend = nullptr) {
 #define GMP_LAUNCH_NV(NV)                                                                                       \
-    hipLaunchKernelGGL((seg_sum_kernel<NV, SELF, IDX, MEAN, ACCUM, DOT>), dim3(p.grid), dim3(BLOCK), 0, st,    \
+    hipLaunchKernelGGL((seg_sum_kernel<NV, SELF, IDX, MEAN, ACCUM, DOT, ADDEND>), dim3(p.grid), dim3(BLOCK), 0, st, \
                        (const float4*)src, ptr, idx, (const float4*)self, eps, (const float4*)dotx, (float4*)out, \
-                       partials, nrows, F4, p.rows_per_wave)
+                       partials, nrows, F4, p.rows_per_wave, (const float4*)addend)
     switch (nv) {
         case 1: GMP_LAUNCH_NV(1); break;
         case 2: GMP_LAUNCH_NV(2); break;
@@ -198,7 +194,7 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
 
 extern "C" size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t N, int feat) {
     (void)feat;
-    return (size_t)make_plan(N > 0 ? N : 1).grid * sizeof(float) + 256;
+    return (size_t)(N > 0 ? N : 1) * sizeof(float) + 256;   // one <g, x> per row, summed in a second pass
 }
 
 extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t,
@@ -218,12 +214,66 @@ extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t
     if (!g_eps)
         return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, st, g_out, rowptr_t, col_t, g_out, eps,
                                                           nullptr, g_x, nullptr, N, F4);
-    if (ws_bytes < (size_t)p.grid * sizeof(float)) return gmp::fail(GMP_ERR_WORKSPACE, "gin_aggregate_bwd: workspace");
+    if (ws_bytes < (size_t)N * sizeof(float)) return gmp::fail(GMP_ERR_WORKSPACE, "gin_aggregate_bwd: workspace");
     int rc = launch_nv<true, true, false, false, true>((F4 + 63) / 64, p, st, g_out, rowptr_t, col_t, g_out, eps, x, g_x,
                                                        (float*)ws, N, F4);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, p.grid, g_eps);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)N, g_eps);
     return gmp::check_launch("reduce_partials_kernel");
+}
+
+// Stacked-pass form: g_x = (1+eps) g + sum over the transposed CSR of g (+ addend), and rowdot[r] = <g[r], x[r]>
+// so the caller can reduce the eps gradient per task (gmp_group_sum_1d).
+extern "C" int gmp_gin_aggregate_bwd_ex(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t, const float* eps,
+                                        const float* x, const float* addend, float* g_x, float* rowdot, int64_t N,
+                                        int feat, gmp_stream_t stream) {
+    if (int rc = check_feat("gin_aggregate_bwd_ex", feat)) return rc;
+    if (N < 0 || (N > 0 && (!g_out || !rowptr_t || !g_x))) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_bwd_ex: null pointer");
+    if (rowdot && !x) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_bwd_ex: rowdot needs x");
+    if (N == 0) return GMP_OK;
+    const int F4 = feat / 4, nv = (F4 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    Plan p = make_plan(N);
+    if (rowdot) {
+        if (addend) return launch_nv<true, true, false, false, true, true>(nv, p, st, g_out, rowptr_t, col_t, g_out, eps, x, g_x, rowdot, N, F4, addend);
+        return launch_nv<true, true, false, false, true, false>(nv, p, st, g_out, rowptr_t, col_t, g_out, eps, x, g_x, rowdot, N, F4);
+    }
+    if (addend) return launch_nv<true, true, false, false, false, true>(nv, p, st, g_out, rowptr_t, col_t, g_out, eps, nullptr, g_x, nullptr, N, F4, addend);
+    return launch_nv<true, true, false, false, false, false>(nv, p, st, g_out, rowptr_t, col_t, g_out, eps, nullptr, g_x, nullptr, N, F4);
+}
+
+namespace {
+struct Groups1d {
+    int n;
+    int row[GMP_MAX_GROUPS + 1];
+    int64_t off[GMP_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void group_sum_1d_kernel(const float* __restrict__ v, Groups1d g, float* out) {
+    __shared__ float sh[256];
+    const int grp = blockIdx.x;
+    float s = 0.f;
+    for (int i = g.row[grp] + threadIdx.x; i < g.row[grp + 1]; i += 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[g.off[grp]] = sh[0];
+}
+}  // namespace
+
+// out[off[g]] = sum of vals[rows[g] .. rows[g+1])  (fixed tree order: deterministic)
+extern "C" int gmp_group_sum_1d(const float* vals, int groups, const int32_t* group_rows_host, const int64_t* out_off_host,
+                                float* out, gmp_stream_t stream) {
+    if (groups < 1 || groups > GMP_MAX_GROUPS || !group_rows_host || !vals || !out)
+        return gmp::fail(GMP_ERR_ARG, "group_sum_1d: bad argument (groups=%d)", groups);
+    Groups1d g{};
+    g.n = groups;
+    for (int i = 0; i <= groups; ++i) g.row[i] = group_rows_host[i];
+    for (int i = 0; i < groups; ++i) g.off[i] = out_off_host ? out_off_host[i] : i;
+    hipLaunchKernelGGL(group_sum_1d_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, vals, g, out);
+    return gmp::check_launch("group_sum_1d_kernel");
 }
 
 extern "C" int gmp_segment_sum(const float* src, const int32_t* ptr, const int32_t* idx, float* out, int64_t nseg,

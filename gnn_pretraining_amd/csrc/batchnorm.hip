@@ -3,9 +3,9 @@
 // A "segment" = the rows of one reference forward() call, so several independent
 // forwards (7 per domain per step in the s4 scheme) share a launch while keeping
 // their own batch statistics.  Two regimes, picked from the longest segment:
-//   short segments (<= SHORT_MAX rows): one workgroup owns (segment, 64 columns),
-//     walks the rows three times out of L2 (mean, centred variance, apply) -- exact
-//     two-pass statistics, no atomics, one launch;
+//   short segments (<= SHORT_MAX rows): one workgroup owns (segment, 32 columns) and
+//     keeps that tile in registers: one read, exact two-pass statistics (mean, then
+//     centred variance), apply, one write -- no atomics, one launch;
 //   long segments (Cora, the roofline ladder): row chunks produce (mean, M2)
 //     partials, combined in chunk order with Chan's formula, then an apply pass.
 // Both are deterministic.  Memory-bound; a thread moves float4.
@@ -25,6 +25,7 @@ struct BnArgs {
     const float* res;
     const float* gy;
     const int* seg_ptr;
+    const int* seg_group;   // nullable: parameter group of each segment (per-domain encoders); gamma/beta/running are [groups][C]
     int S;
     int C;
     const float* gamma;
@@ -85,35 +86,63 @@ __device__ __forceinline__ float4 bn_apply(const BnArgs& a, float4 u, float4 mea
     return y;
 }
 
+__device__ __forceinline__ int64_t pgrp(const BnArgs& a, int s) { return a.seg_group ? (int64_t)a.seg_group[s] * a.C : 0; }
+
 __device__ __forceinline__ void stats_for(const BnArgs& a, int s, int c, float4* mean, float4* rstd) {
     if (a.cfg.training) {
         *mean = ld4(a.save_mean + (int64_t)s * a.C + c);
         *rstd = ld4(a.save_rstd + (int64_t)s * a.C + c);
     } else {
-        *mean = ld4(a.running_mean + c);
-        float4 v = ld4(a.running_var + c);
+        *mean = ld4(a.running_mean + pgrp(a, s) + c);
+        float4 v = ld4(a.running_var + pgrp(a, s) + c);
         *rstd = make_float4(rsqrtf(v.x + a.cfg.eps), rsqrtf(v.y + a.cfg.eps), rsqrtf(v.z + a.cfg.eps), rsqrtf(v.w + a.cfg.eps));
     }
 }
 
 // ------------------------------------------------------------ short regime, fwd
+// Register-resident: a workgroup owns (segment, 32 columns); its 256 threads are 8 column quads x 32 row
+// lanes and each thread keeps its <= RPT rows of the tile in registers, so the tile is read from memory
+// ONCE with every load in flight together, instead of three latency-bound sweeps.
+constexpr int SCOLS = 32, SCQ = SCOLS / 4, SRL = THREADS / SCQ;   // 8 quads x 32 row lanes
+
+template <int RL_, int CQ_>
+__device__ __forceinline__ float4 colsum_t(float4 v, float4 (*sh)[CQ_], int rl, int cq) {
+    __syncthreads();
+    sh[rl][cq] = v;
+    __syncthreads();
+    float4 s = sh[0][cq];
+#pragma unroll
+    for (int i = 1; i < RL_; ++i) s = add4(s, sh[i][cq]);
+    return s;
+}
+
+template <int RPT>
 __global__ __launch_bounds__(THREADS) void bn_fwd_short_kernel(BnArgs a) {
-    __shared__ float4 sh[RL][CQ];
-    const int s = blockIdx.x, cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-    const int c = blockIdx.y * COLS + cq * 4;
+    __shared__ float4 sh[SRL][SCQ];
+    const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
+    const int c = blockIdx.y * SCOLS + cq * 4;
     const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
     if (n <= 0) return;
+    float4 u[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        u[i] = r < r1 ? load_u(a, (int64_t)r * a.C + c) : zero4();
+    }
     float4 mean, rstd;
     if (a.cfg.training) {
         float4 acc = zero4();
-        for (int r = r0 + rl; r < r1; r += RL) acc = add4(acc, load_u(a, (int64_t)r * a.C + c));
-        mean = scl4(block_colsum(acc, sh, rl, cq), 1.f / n);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) acc = add4(acc, u[i]);
+        mean = scl4(colsum_t<SRL, SCQ>(acc, sh, rl, cq), 1.f / n);
         acc = zero4();
-        for (int r = r0 + rl; r < r1; r += RL) {
-            float4 d = sub4(load_u(a, (int64_t)r * a.C + c), mean);
-            acc = add4(acc, mul4(d, d));
-        }
-        float4 var = scl4(block_colsum(acc, sh, rl, cq), 1.f / n);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            if (r0 + rl + i * SRL < r1) {
+                float4 d = sub4(u[i], mean);
+                acc = add4(acc, mul4(d, d));
+            }
+        float4 var = scl4(colsum_t<SRL, SCQ>(acc, sh, rl, cq), 1.f / n);
         rstd = make_float4(rsqrtf(var.x + a.cfg.eps), rsqrtf(var.y + a.cfg.eps), rsqrtf(var.z + a.cfg.eps), rsqrtf(var.w + a.cfg.eps));
         if (rl == 0) {
             st4(a.save_mean + (int64_t)s * a.C + c, mean);
@@ -122,11 +151,15 @@ __global__ __launch_bounds__(THREADS) void bn_fwd_short_kernel(BnArgs a) {
     } else {
         stats_for(a, s, c, &mean, &rstd);
     }
-    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const int64_t off = (int64_t)r * a.C + c;
-        float4 gate;
-        st4(a.y + off, bn_apply(a, load_u(a, off), mean, rstd, gam, bet, off >> 2, &gate));
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        if (r < r1) {
+            const int64_t off = (int64_t)r * a.C + c;
+            float4 gate;
+            st4(a.y + off, bn_apply(a, u[i], mean, rstd, gam, bet, off >> 2, &gate));
+        }
     }
 }
 
@@ -134,19 +167,17 @@ __global__ __launch_bounds__(THREADS) void bn_fwd_short_kernel(BnArgs a) {
 __global__ __launch_bounds__(THREADS) void bn_running_kernel(BnArgs a) {
     const int c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.C) return;
-    float rm = a.running_mean[c], rv = a.running_var[c];
     const float m = a.cfg.momentum;
-    for (int s = 0; s < a.S; ++s) {
+    for (int s = 0; s < a.S; ++s) {      // one thread owns column c of every group: sequential, race-free
         const int n = a.seg_ptr[s + 1] - a.seg_ptr[s];
         if (n <= 0) continue;
+        const int64_t o = pgrp(a, s) + c;
         const float mean = a.save_mean[(int64_t)s * a.C + c], rstd = a.save_rstd[(int64_t)s * a.C + c];
         const float var = 1.f / (rstd * rstd) - a.cfg.eps;   // biased batch variance
         const float unb = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
-        rm = (1.f - m) * rm + m * mean;
-        rv = (1.f - m) * rv + m * unb;
+        a.running_mean[o] = (1.f - m) * a.running_mean[o] + m * mean;
+        a.running_var[o] = (1.f - m) * a.running_var[o] + m * unb;
     }
-    a.running_mean[c] = rm;
-    a.running_var[c] = rv;
 }
 
 // ------------------------------------------------------------- long regime, fwd
@@ -202,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void bn_apply_long_kernel(BnArgs a) {
     if (r0 >= seg1) return;
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
-    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
     for (int r = r0 + rl; r < r1; r += RL) {
         const int64_t off = (int64_t)r * a.C + c;
         float4 gate;
@@ -229,10 +260,11 @@ __device__ __forceinline__ float4 bwd_input(const BnArgs& a, float4 gaff, float4
                        k.z * (gaff.z - s1.z * inv_n - xhat.z * s2.z * inv_n), k.w * (gaff.w - s1.w * inv_n - xhat.w * s2.w * inv_n));
 }
 
+template <int RPT>
 __global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
-    __shared__ float4 sh[RL][CQ];
-    const int s = blockIdx.x, cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-    const int c = blockIdx.y * COLS + cq * 4;
+    __shared__ float4 sh[SRL][SCQ];
+    const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
+    const int c = blockIdx.y * SCOLS + cq * 4;
     const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
     float* ss = a.segsum + (int64_t)s * 2 * a.C + c;
     if (n <= 0) {
@@ -241,23 +273,27 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
     }
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
-    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
+    float4 xh[RPT], ga[RPT];
     float4 a1 = zero4(), a2 = zero4();
-    for (int r = r0 + rl; r < r1; r += RL) {
-        float4 g, xh;
-        bwd_elem(a, (int64_t)r * a.C + c, mean, rstd, gam, bet, &g, &xh);
-        a1 = add4(a1, g);
-        a2 = add4(a2, mul4(g, xh));
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        xh[i] = zero4(); ga[i] = zero4();
+        if (r < r1) {
+            bwd_elem(a, (int64_t)r * a.C + c, mean, rstd, gam, bet, &ga[i], &xh[i]);
+            a1 = add4(a1, ga[i]);
+            a2 = add4(a2, mul4(ga[i], xh[i]));
+        }
     }
-    const float4 s1 = block_colsum(a1, sh, rl, cq);
-    const float4 s2 = block_colsum(a2, sh, rl, cq);
+    const float4 s1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
+    const float4 s2 = colsum_t<SRL, SCQ>(a2, sh, rl, cq);
     if (rl == 0) { st4(ss, s1); st4(ss + a.C, s2); }
     const float inv_n = 1.f / n;
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const int64_t off = (int64_t)r * a.C + c;
-        float4 g, xh;
-        bwd_elem(a, off, mean, rstd, gam, bet, &g, &xh);
-        st4(a.y + off, bwd_input(a, g, xh, s1, s2, gam, rstd, inv_n));
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        if (r < r1) st4(a.y + (int64_t)r * a.C + c, bwd_input(a, ga[i], xh[i], s1, s2, gam, rstd, inv_n));
     }
 }
 
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_partial_kernel(BnArgs a) {
     if (r0 >= seg1) return;
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
-    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
     float4 a1 = zero4(), a2 = zero4();
     for (int r = r0 + rl; r < r1; r += RL) {
         float4 g, xh;
@@ -309,7 +345,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_long_kernel(BnArgs a) {
     if (r0 >= seg1) return;
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
-    const float4 gam = ld4(a.gamma + c), bet = ld4(a.beta + c);
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
     const float4 s1 = ld4(a.segsum + (int64_t)s * 2 * a.C + c), s2 = ld4(a.segsum + (int64_t)s * 2 * a.C + a.C + c);
     const float inv_n = 1.f / (seg1 - seg0);
     for (int r = r0 + rl; r < r1; r += RL) {
@@ -320,18 +356,24 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_long_kernel(BnArgs a) {
     }
 }
 
-// g_gamma[grp] = sum over the group's segments of sum(g*xhat); g_beta likewise.  [lo,hi) segments.
-__global__ __launch_bounds__(THREADS) void bn_param_grad_kernel(const float* __restrict__ segsum, int C, int lo, int hi,
+// g_gamma[grp] = sum over the group's segments of sum(g*xhat); g_beta likewise.  blockIdx.y = group;
+// outputs land at base + out_off[grp] (offsets into the per-task gradient buffer).
+struct BnGroups {
+    int n;
+    int seg[GMP_MAX_GROUPS + 1];
+    int64_t off_gamma[GMP_MAX_GROUPS], off_beta[GMP_MAX_GROUPS];
+};
+__global__ __launch_bounds__(THREADS) void bn_param_grad_kernel(const float* __restrict__ segsum, int C, BnGroups grp,
                                                                 float* g_gamma, float* g_beta) {
-    const int c = blockIdx.x * THREADS + threadIdx.x;
+    const int c = blockIdx.x * THREADS + threadIdx.x, g = blockIdx.y;
     if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int s = lo; s < hi; ++s) {
+    for (int s = grp.seg[g]; s < grp.seg[g + 1]; ++s) {
         s1 += segsum[(int64_t)s * 2 * C + c];
         s2 += segsum[(int64_t)s * 2 * C + C + c];
     }
-    g_beta[c] = s1;
-    g_gamma[c] = s2;
+    g_beta[grp.off_beta[g] + c] = s1;
+    g_gamma[grp.off_gamma[g] + c] = s2;
 }
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -356,8 +398,15 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
     return b + 256;
 }
 
-extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, int S, int64_t max_seg_rows,
-                          int64_t rows, int C, const float* gamma, const float* beta, float* running_mean,
+#define GMP_BN_SHORT_LAUNCH(KERNEL, MAXROWS, GRID, BLK, ST, ARGS)                      \
+    do {                                                                               \
+        if ((MAXROWS) <= 4 * SRL) hipLaunchKernelGGL(KERNEL<4>, GRID, BLK, 0, ST, ARGS);      \
+        else if ((MAXROWS) <= 8 * SRL) hipLaunchKernelGGL(KERNEL<8>, GRID, BLK, 0, ST, ARGS); \
+        else hipLaunchKernelGGL(KERNEL<16>, GRID, BLK, 0, ST, ARGS);                   \
+    } while (0)
+
+extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group, int S,
+                          int64_t max_seg_rows, int64_t rows, int C, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float* save_mean, float* save_rstd, float* y, const gmp_bn_config* cfg,
                           void* ws, size_t ws_bytes, gmp_stream_t stream) {
     if (int rc = common_check("bn_fwd", rows, C, S, max_seg_rows, cfg)) return rc;
@@ -368,14 +417,14 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     if (ws_bytes < gmp_bn_workspace_bytes(rows, C, S, max_seg_rows) || !ws) return gmp::fail(GMP_ERR_WORKSPACE, "bn_fwd: workspace");
     hipStream_t st = (hipStream_t)stream;
     BnArgs a{};
-    a.x = x; a.res = residual; a.seg_ptr = seg_ptr; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
+    a.x = x; a.res = residual; a.seg_ptr = seg_ptr; a.seg_group = seg_group; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
     a.running_mean = running_mean; a.running_var = running_var; a.save_mean = save_mean; a.save_rstd = save_rstd;
     a.y = y; a.cfg = *cfg;
     a.part = (float*)((char*)ws + al((size_t)S * 2 * C * sizeof(float)));
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        hipLaunchKernelGGL(bn_fwd_short_kernel, dim3(S, C / COLS), blk, 0, st, a);
+        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         if (cfg->training) {
@@ -389,19 +438,21 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     return gmp::check_launch("bn_fwd kernels");
 }
 
-extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr, int S,
-                          int64_t max_seg_rows, int64_t rows, int C, const float* gamma, const float* beta,
-                          const float* running_mean, const float* running_var, const float* save_mean,
+extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr,
+                          const int32_t* seg_group, int S, int64_t max_seg_rows, int64_t rows, int C, const float* gamma,
+                          const float* beta, const float* running_mean, const float* running_var, const float* save_mean,
                           const float* save_rstd, float* g_u, float* g_gamma, float* g_beta,
-                          const int32_t* grp_seg_ptr_host, int G, const gmp_bn_config* cfg, void* ws, size_t ws_bytes,
+                          const int32_t* grp_seg_ptr_host, const int64_t* grp_off_gamma_host,
+                          const int64_t* grp_off_beta_host, int G, const gmp_bn_config* cfg, void* ws, size_t ws_bytes,
                           gmp_stream_t stream) {
     if (int rc = common_check("bn_bwd", rows, C, S, max_seg_rows, cfg)) return rc;
-    if (G < 0 || (G > 0 && (!grp_seg_ptr_host || !g_gamma || !g_beta))) return gmp::fail(GMP_ERR_ARG, "bn_bwd: group arguments");
+    if (G < 0 || G > GMP_MAX_GROUPS || (G > 0 && (!grp_seg_ptr_host || !g_gamma || !g_beta)))
+        return gmp::fail(GMP_ERR_ARG, "bn_bwd: group arguments (G=%d, max %d)", G, GMP_MAX_GROUPS);
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0 || S == 0) {
-        if (G > 0) {
-            (void)hipMemsetAsync(g_gamma, 0, (size_t)G * C * sizeof(float), st);
-            (void)hipMemsetAsync(g_beta, 0, (size_t)G * C * sizeof(float), st);
+        for (int g = 0; g < G; ++g) {
+            (void)hipMemsetAsync(g_gamma + (grp_off_gamma_host ? grp_off_gamma_host[g] : (int64_t)g * C), 0, (size_t)C * sizeof(float), st);
+            (void)hipMemsetAsync(g_beta + (grp_off_beta_host ? grp_off_beta_host[g] : (int64_t)g * C), 0, (size_t)C * sizeof(float), st);
         }
         return GMP_OK;
     }
@@ -413,7 +464,7 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
         if (grp_seg_ptr_host[g] < 0 || grp_seg_ptr_host[g] > grp_seg_ptr_host[g + 1] || grp_seg_ptr_host[g + 1] > S)
             return gmp::fail(GMP_ERR_ARG, "bn_bwd: group %d covers segments [%d,%d) of %d", g, grp_seg_ptr_host[g], grp_seg_ptr_host[g + 1], S);
     BnArgs a{};
-    a.x = x; a.res = residual; a.gy = g_y; a.seg_ptr = seg_ptr; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
+    a.x = x; a.res = residual; a.gy = g_y; a.seg_ptr = seg_ptr; a.seg_group = seg_group; a.S = S; a.C = C; a.gamma = gamma; a.beta = beta;
     a.running_mean = (float*)running_mean; a.running_var = (float*)running_var;
     a.save_mean = (float*)save_mean; a.save_rstd = (float*)save_rstd; a.y = g_u; a.cfg = *cfg;
     a.segsum = (float*)ws;
@@ -421,15 +472,23 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        hipLaunchKernelGGL(bn_bwd_short_kernel, dim3(S, C / COLS), blk, 0, st, a);
+        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, blk, 0, st, a);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + THREADS - 1) / THREADS, S), blk, 0, st, a);
         hipLaunchKernelGGL(bn_bwd_apply_long_kernel, grid, blk, 0, st, a);
     }
-    for (int g = 0; g < G; ++g)
-        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + THREADS - 1) / THREADS), blk, 0, st, (const float*)a.segsum, C,
-                           grp_seg_ptr_host[g], grp_seg_ptr_host[g + 1], g_gamma + (size_t)g * C, g_beta + (size_t)g * C);
+    if (G > 0) {
+        BnGroups grp{};
+        grp.n = G;
+        for (int g = 0; g <= G; ++g) grp.seg[g] = grp_seg_ptr_host[g];
+        for (int g = 0; g < G; ++g) {
+            grp.off_gamma[g] = grp_off_gamma_host ? grp_off_gamma_host[g] : (int64_t)g * C;
+            grp.off_beta[g] = grp_off_beta_host ? grp_off_beta_host[g] : (int64_t)g * C;
+        }
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + THREADS - 1) / THREADS, G), blk, 0, st, (const float*)a.segsum, C, grp,
+                           g_gamma, g_beta);
+    }
     return gmp::check_launch("bn_bwd kernels");
 }

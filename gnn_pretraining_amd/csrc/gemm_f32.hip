@@ -84,6 +84,8 @@ struct TileLoader {
     }
 };
 
+constexpr int MAXG = GMP_MAX_GROUPS;
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -95,6 +97,16 @@ struct GemmArgs {
     int splitk;           // >1: blockIdx.z = k-slice, partial tiles go to `partial` [splitk][M][N]
     float* partial;
     int vecA, vecB;
+    // grouped form (groups > 0): blockIdx.z = group.  NT/NN: group g owns rows [grow[g], grow[g+1]) of A and C and
+    // its own weight matrix B + boff[g] (and bias + biasoff[g]).  TN: group g reduces over rows [grow[g], grow[g+1])
+    // of A and B into its own output C + coff[g].
+    int groups;
+    int grow[MAXG + 1];
+    int64_t boff[MAXG], biasoff[MAXG], coff[MAXG];
+    // grouped TN only: asum + asumoff[g] receives sum over the group's rows of A[:, m] (the bias gradient
+    // g^T 1 rides along with the weight gradient g^T x: the A tile is already in LDS)
+    float* asum;
+    int64_t asumoff[MAXG];
 };
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
@@ -107,11 +119,25 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 
     const int t = threadIdx.x, lane = t % 64, wv = t / 64;
     const int wm = wv / 2, wn = wv % 2, l31 = lane & 31, half = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int64_t n0 = (int64_t)blockIdx.x * BN;
 
     // k range of this block (split-K slices are multiples of BK)
     int64_t kbeg = 0, kend = g.K;
-    if (g.splitk > 1) {
+    if (g.groups > 0) {
+        const int grp = blockIdx.z;
+        if (A_KMAJOR && B_KMAJOR) {            // TN: reduction range = the group's rows
+            kbeg = g.grow[grp];
+            kend = g.grow[grp + 1];
+            g.C += g.coff[grp];
+        } else {                                // NT / NN: row range of A and C, per-group B (and bias)
+            m0 += g.grow[grp];
+            g.M = g.grow[grp + 1];
+            if (m0 >= g.M) return;
+            g.B += g.boff[grp];
+            if (g.bias) g.bias += g.biasoff[grp];
+        }
+    } else if (g.splitk > 1) {
         const int64_t steps = (g.K + BK - 1) / BK;
         const int64_t per = (steps + g.splitk - 1) / g.splitk;
         kbeg = (int64_t)blockIdx.z * per * BK;
@@ -126,6 +152,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float colacc = 0.f;
+    const bool want_asum = A_KMAJOR && B_KMAJOR && g.groups > 0 && g.asum != nullptr && blockIdx.x == 0;
     LA la;
     LB lb;
     if (kbeg < kend) {
@@ -136,6 +164,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
         la.store(As, t);
         lb.store(Bs, t);
         __syncthreads();
+        if (want_asum && t < BM) {
+#pragma unroll 8
+            for (int kk = 0; kk < BK; ++kk) colacc += As[kk * LA::LD + t];
+        }
         if (k0 + BK < kend) {   // prefetch the next K-step while this one is multiplied
             la.load(g.A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, t);
             lb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t);
@@ -155,6 +187,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
+
+    if (want_asum && t < BM && m0 + t < g.M) g.asum[g.asumoff[blockIdx.z] + m0 + t] = colacc;
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* out = g.C;
@@ -283,6 +317,49 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
         return gmp::check_launch("splitk_reduce_kernel");
     }
     return GMP_OK;
+}
+
+extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, const float* bias, float* C, int groups,
+                                    const int32_t* group_rows_host, const int64_t* b_off_host,
+                                    const int64_t* bias_off_host, const int64_t* c_off_host, float* a_colsum,
+                                    const int64_t* a_colsum_off_host, int64_t M_tn, int64_t N, int64_t K, int64_t lda,
+                                    int64_t ldb, int64_t ldc, float alpha, int accumulate, int relu,
+                                    gmp_stream_t stream) {
+    if (mode < 0 || mode > 2) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: mode %d", mode);
+    if (groups < 1 || groups > MAXG || !group_rows_host) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: %d groups (max %d)", groups, MAXG);
+    if (N <= 0 || K < 0 || !A || !B || !C) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: bad argument");
+    GemmArgs g{};
+    g.A = A; g.B = B; g.bias = bias; g.C = C; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = alpha; g.accumulate = accumulate; g.relu = relu; g.splitk = 1; g.partial = nullptr;
+    g.vecA = (lda % 4 == 0) && aligned16(A);
+    g.vecB = (ldb % 4 == 0) && aligned16(B);
+    g.groups = groups;
+    g.asum = mode == GMP_GEMM_TN ? a_colsum : nullptr;
+    int64_t max_rows = 0;
+    for (int i = 0; i <= groups; ++i) {
+        g.grow[i] = group_rows_host[i];
+        if (i && (g.grow[i] < g.grow[i - 1] || g.grow[i - 1] < 0)) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: group rows not ascending");
+        if (i) max_rows = std::max<int64_t>(max_rows, g.grow[i] - g.grow[i - 1]);
+    }
+    for (int i = 0; i < groups; ++i) {
+        g.boff[i] = b_off_host ? b_off_host[i] : 0;
+        g.biasoff[i] = bias_off_host ? bias_off_host[i] : 0;
+        g.coff[i] = c_off_host ? c_off_host[i] : 0;
+        g.asumoff[i] = a_colsum_off_host ? a_colsum_off_host[i] : (int64_t)i * M_tn;
+        if ((g.boff[i] % 4) || (g.coff[i] % 4)) g.vecB = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == GMP_GEMM_TN) {
+        g.M = M_tn;          // output rows = columns of A (k-major A: lda >= M_tn); the reduction runs over the group's rows
+        g.K = 0;
+        if (g.M == 0) return GMP_OK;
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)groups), st);
+    } else {
+        if (max_rows == 0) return GMP_OK;
+        g.M = 0;
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((max_rows + 63) / 64), (unsigned)groups), st);
+    }
+    return gmp::check_launch("gemm_kernel (grouped)");
 }
 
 extern "C" size_t gmp_colsum_workspace_bytes(int64_t M, int64_t N) {

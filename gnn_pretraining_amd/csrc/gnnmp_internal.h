@@ -8,6 +8,7 @@
 #include "../../include/gnnmp.h"
 
 #define GMP_WAVE 64
+#define GMP_MAX_GROUPS 24
 
 namespace gmp {
 

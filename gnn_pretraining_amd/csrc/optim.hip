@@ -1,0 +1,271 @@
+// Multi-tensor PCGrad + gradient clipping + AdamW over flat buffers: the tail of every optimisation
+// step (reference src/pretrain/gradient_surgery.py:41-103, pretrain.py:152-153, optimizers.py:8-75).
+//
+// The reference walks ~62 shared tensors x 10 task pairs with three host syncs each (norm()==0,
+// dot<0) -- about 1,900 device->host round trips per s4 step.  Here the whole thing is five launches:
+//   gram     one block per tensor: every <g_i, g_j> of that tensor              (per-tensor, not whole-model,
+//   solve    one thread per tensor: PCGrad's sequential projections solved in    exactly as the reference)
+//            5x5 Gram space -> per-task mixing weights, plus the reference's
+//            "which tensors get a gradient at all" rule (its _set_gradients quirk)
+//   combine  final = sum_t w[k][t] * g_t, and the per-block sums of squares for the clip norm
+//   norm     one block: total squared norm (fixed order)
+//   adamw    clip coefficient + decoupled weight decay + Adam, per-tensor lr / step count
+// Everything is deterministic (no atomics).
+#include "gnnmp_internal.h"
+
+namespace {
+
+constexpr int MAXT = 8;        // tasks
+constexpr int CH = 8;          // chunks per tensor in the elementwise kernels
+constexpr int TB = 256;
+
+struct MtArgs {
+    const float* tg;           // [T][stride] per-task gradients
+    int64_t stride;
+    int T, K;
+    const int64_t* off;        // [K]
+    const int* len;            // [K]
+    const unsigned char* has;  // [K][MAXT]
+    double* gram;              // [K][MAXT][MAXT]
+    float* weights;            // [K][MAXT]
+    int* flags;                // [K]
+    float* steps;              // [K]
+    int* metrics;              // [2] conflicts, projections
+    int order[MAXT];           // shuffled task order
+    int n_order;               // tasks taking part in PCGrad
+    int last_task;             // last task in dict order (keeps its raw .grad where PCGrad emits nothing)
+    int extra_task;            // -1, or a task whose gradient is ADDED afterwards (domain_adv in s5)
+    float* final_grad;         // [P]
+    float* partial;            // [K*CH]
+    float* normsq;             // [1]
+    float* params;
+    float* exp_avg;
+    float* exp_avg_sq;
+    const float* lr;           // [K]
+    const float* wd;           // [K]
+    float beta1, beta2, eps, max_norm;
+};
+
+__global__ __launch_bounds__(TB) void gram_kernel(MtArgs a) {
+    const int k = blockIdx.x;
+    int holders[MAXT], nh = 0;
+    for (int t = 0; t < a.T; ++t)
+        if (a.has[k * MAXT + t]) holders[nh++] = t;
+    if (nh < 2) return;                         // nothing to project against
+    float acc[MAXT * (MAXT + 1) / 2];
+    const int npair = nh * (nh + 1) / 2;
+    for (int p = 0; p < npair; ++p) acc[p] = 0.f;
+    const int64_t off = a.off[k];
+    __shared__ double sh[TB];
+    double tot[MAXT * (MAXT + 1) / 2];
+    for (int p = 0; p < npair; ++p) tot[p] = 0.0;
+    // fp32 partials over short strips, widened to double before they are combined
+    for (int base = 0; base < a.len[k]; base += TB * 64) {
+        for (int p = 0; p < npair; ++p) acc[p] = 0.f;
+        for (int i = base + threadIdx.x; i < a.len[k] && i < base + TB * 64; i += TB) {
+            float g[MAXT];
+            for (int h = 0; h < nh; ++h) g[h] = a.tg[(int64_t)holders[h] * a.stride + off + i];
+            int p = 0;
+            for (int x = 0; x < nh; ++x)
+                for (int y = x; y < nh; ++y) acc[p++] += g[x] * g[y];
+        }
+        for (int p = 0; p < npair; ++p) tot[p] += (double)acc[p];
+    }
+    int p = 0;
+    for (int x = 0; x < nh; ++x)
+        for (int y = x; y < nh; ++y, ++p) {
+            __syncthreads();
+            sh[threadIdx.x] = tot[p];
+            __syncthreads();
+            for (int d = TB / 2; d > 0; d >>= 1) {
+                if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                a.gram[((int64_t)k * MAXT + holders[x]) * MAXT + holders[y]] = sh[0];
+                a.gram[((int64_t)k * MAXT + holders[y]) * MAXT + holders[x]] = sh[0];
+            }
+        }
+}
+
+__global__ __launch_bounds__(TB) void solve_kernel(MtArgs a) {
+    __shared__ int s_conf[TB], s_proj[TB];
+    int conf = 0, proj = 0;
+    for (int k = threadIdx.x; k < a.K; k += TB) {
+        const unsigned char* has = a.has + k * MAXT;
+        const double* G = a.gram + (int64_t)k * MAXT * MAXT;
+        float w[MAXT];
+        for (int t = 0; t < MAXT; ++t) w[t] = 0.f;
+        int flag = 0;
+        const int first = a.order[0];
+        if (has[first]) {
+            double alpha[MAXT][MAXT];
+            for (int i = 0; i < a.T; ++i)
+                for (int j = 0; j < a.T; ++j) alpha[i][j] = i == j ? 1.0 : 0.0;
+            for (int i = 0; i < a.n_order; ++i) {
+                const int ti = a.order[i];
+                if (!has[ti]) continue;
+                for (int j = 0; j < i; ++j) {
+                    const int tj = a.order[j];
+                    if (!has[tj]) continue;
+                    double ni = 0.0;          // only holder x holder entries of G are ever written
+                    for (int p = 0; p < a.T; ++p)
+                        for (int q = 0; q < a.T; ++q)
+                            if (has[p] && has[q]) ni += alpha[ti][p] * alpha[ti][q] * G[p * MAXT + q];
+                    const double nj = G[tj * MAXT + tj];
+                    if (ni <= 0.0 || nj <= 0.0) continue;          // reference: norm() == 0 -> skip the pair
+                    ++proj;
+                    double dot = 0.0;
+                    for (int p = 0; p < a.T; ++p)
+                        if (has[p]) dot += alpha[ti][p] * G[p * MAXT + tj];
+                    if (dot < 0.0) {
+                        ++conf;
+                        alpha[ti][tj] -= dot / nj;                 // project off task j's ORIGINAL gradient
+                    }
+                }
+            }
+            int nh = 0;
+            for (int i = 0; i < a.n_order; ++i) nh += has[a.order[i]] ? 1 : 0;
+            for (int i = 0; i < a.n_order; ++i) {
+                const int ti = a.order[i];
+                if (!has[ti]) continue;
+                for (int b = 0; b < a.T; ++b) w[b] += (float)(alpha[ti][b] / nh);
+            }
+            flag = 1;
+        } else if (a.last_task >= 0 && has[a.last_task]) {
+            w[a.last_task] = 1.f;      // untouched by _set_gradients: keeps the last backward's .grad
+            flag = 1;
+        }
+        if (a.extra_task >= 0 && has[a.extra_task]) {
+            w[a.extra_task] += 1.f;    // domain_adv_loss.backward() accumulates on top (pretrain.py:149-150)
+            flag = 1;
+        }
+        for (int t = 0; t < MAXT; ++t) a.weights[k * MAXT + t] = w[t];
+        a.flags[k] = flag;
+        if (a.steps) a.steps[k] += (float)flag;     // torch.optim keeps a per-parameter step that only advances with a gradient
+    }
+    s_conf[threadIdx.x] = conf;
+    s_proj[threadIdx.x] = proj;
+    __syncthreads();
+    for (int d = TB / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            s_conf[threadIdx.x] += s_conf[threadIdx.x + d];
+            s_proj[threadIdx.x] += s_proj[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.metrics[0] = s_conf[0];
+        a.metrics[1] = s_proj[0];
+    }
+}
+
+__global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
+    __shared__ float sh[TB];
+    const int k = blockIdx.x, j = blockIdx.y;
+    float ss = 0.f;
+    if (a.flags[k]) {
+        float w[MAXT];
+        for (int t = 0; t < MAXT; ++t) w[t] = a.weights[k * MAXT + t];
+        const int len = a.len[k], per = (len + CH - 1) / CH;
+        const int lo = j * per, hi = min(lo + per, len);
+        const int64_t off = a.off[k];
+        for (int i = lo + threadIdx.x; i < hi; i += TB) {
+            float g = 0.f;
+            for (int t = 0; t < a.T; ++t)
+                if (w[t] != 0.f) g = fmaf(w[t], a.tg[(int64_t)t * a.stride + off + i], g);
+            a.final_grad[off + i] = g;
+            ss = fmaf(g, g, ss);
+        }
+    }
+    sh[threadIdx.x] = ss;
+    __syncthreads();
+    for (int d = TB / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[k * CH + j] = sh[0];
+}
+
+__global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
+    __shared__ double sh[TB];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.K * CH; i += TB) s += (double)a.partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = TB / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.normsq[0] = (float)sh[0];
+}
+
+__global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
+    const int k = blockIdx.x, j = blockIdx.y;
+    if (!a.flags[k]) return;                                   // grad is None: torch skips the parameter entirely
+    // clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); max_norm <= 0 disables clipping
+    float coef = 1.f;
+    if (a.max_norm > 0.f) coef = fminf(1.f, a.max_norm / (sqrtf(a.normsq[0]) + 1e-6f));
+    const float lr = a.lr[k], wd = a.wd[k], step = a.steps[k];
+    const float bc1 = 1.f - powf(a.beta1, step), bc2 = 1.f - powf(a.beta2, step);
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    const int len = a.len[k], per = (len + CH - 1) / CH;
+    const int lo = j * per, hi = min(lo + per, len);
+    const int64_t off = a.off[k];
+    for (int i = lo + threadIdx.x; i < hi; i += TB) {
+        const float g = a.final_grad[off + i] * coef;
+        float p = a.params[off + i] * (1.f - lr * wd);
+        const float m = a.exp_avg[off + i] + (g - a.exp_avg[off + i]) * (1.f - a.beta1);       // lerp_
+        const float v = a.exp_avg_sq[off + i] * a.beta2 + g * g * (1.f - a.beta2);
+        a.exp_avg[off + i] = m;
+        a.exp_avg_sq[off + i] = v;
+        p -= step_size * (m / (sqrtf(v) / bc2s + a.eps));
+        a.params[off + i] = p;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gmp_mt_workspace_bytes(int num_tensors) {
+    const size_t K = num_tensors > 0 ? num_tensors : 0;
+    return K * MAXT * MAXT * sizeof(double) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) + 1024;
+}
+
+extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
+                                        const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
+                                        const int32_t* order_host, int n_order, int last_task, int extra_task,
+                                        float* params, float* exp_avg, float* exp_avg_sq, float* steps,
+                                        const float* lr, const float* wd, float beta1, float beta2, float eps,
+                                        float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
+                                        int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
+                                        gmp_stream_t stream) {
+    if (num_tasks < 1 || num_tasks > MAXT || num_tensors < 1 || n_order < 1 || n_order > num_tasks)
+        return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tasks=%d tensors=%d n_order=%d", num_tasks, num_tensors, n_order);
+    if (!task_grads || !tensor_off || !tensor_len || !has || !order_host || !final_grad || !normsq_out || !metrics_out || !flags_out || !ws)
+        return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: null pointer");
+    if (apply_update && (!params || !exp_avg || !exp_avg_sq || !steps || !lr || !wd)) return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: optimizer state");
+    if (ws_bytes < gmp_mt_workspace_bytes(num_tensors)) return gmp::fail(GMP_ERR_WORKSPACE, "mt_pcgrad: workspace");
+    if (last_task >= num_tasks || extra_task >= num_tasks) return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: task index");
+    MtArgs a{};
+    a.tg = task_grads; a.stride = task_stride; a.T = num_tasks; a.K = num_tensors; a.off = tensor_off; a.len = tensor_len;
+    a.has = has;
+    char* w = (char*)ws;
+    a.gram = (double*)w; w += (size_t)num_tensors * MAXT * MAXT * sizeof(double);
+    a.weights = (float*)w; w += (size_t)num_tensors * MAXT * sizeof(float);
+    a.partial = (float*)w; w += (size_t)num_tensors * CH * sizeof(float);
+    a.flags = flags_out; a.steps = steps; a.metrics = metrics_out;
+    for (int i = 0; i < n_order; ++i) {
+        if (order_host[i] < 0 || order_host[i] >= num_tasks) return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: order[%d]=%d", i, order_host[i]);
+        a.order[i] = order_host[i];
+    }
+    a.n_order = n_order; a.last_task = last_task; a.extra_task = extra_task;
+    a.final_grad = final_grad; a.normsq = normsq_out; a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
+    a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_order > 1) hipLaunchKernelGGL(gram_kernel, dim3(num_tensors), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL(combine_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
+    if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
+    return gmp::check_launch("mt_pcgrad_clip_adamw kernels");
+}

@@ -231,7 +231,7 @@ def bn_fwd(x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, max_seg_rows:
         sr = torch.empty(S, Cc, dtype=torch.float32, device=x.device)
     l = L.lib()
     ws = _ws(l.gmp_bn_workspace_bytes(rows, Cc, S, max_seg_rows), x.device)
-    L.check(l.gmp_bn_fwd(_ptr(x), _ptr(residual), _ptr(seg_ptr), S, max_seg_rows, rows, Cc, _ptr(gamma), _ptr(beta),
+    L.check(l.gmp_bn_fwd(_ptr(x), _ptr(residual), _ptr(seg_ptr), None, S, max_seg_rows, rows, Cc, _ptr(gamma), _ptr(beta),
                          _ptr(running_mean), _ptr(running_var), _ptr(sm), _ptr(sr), _ptr(y), C.byref(cfg),
                          _ptr(ws), ws.numel(), _stream(x)), "gmp_bn_fwd")
     return y, sm, sr
@@ -251,9 +251,9 @@ def bn_bwd(g_y: Tensor, x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, 
     gb = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
     l = L.lib()
     ws = _ws(l.gmp_bn_workspace_bytes(rows, Cc, S, max_seg_rows), x.device)
-    L.check(l.gmp_bn_bwd(_ptr(g_y), _ptr(x), _ptr(residual), _ptr(seg_ptr), S, max_seg_rows, rows, Cc, _ptr(gamma),
+    L.check(l.gmp_bn_bwd(_ptr(g_y), _ptr(x), _ptr(residual), _ptr(seg_ptr), None, S, max_seg_rows, rows, Cc, _ptr(gamma),
                          _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_rstd),
-                         _ptr(g_u), _ptr(gg), _ptr(gb), C.cast(arr, C.c_void_p), G, C.byref(cfg), _ptr(ws), ws.numel(),
+                         _ptr(g_u), _ptr(gg), _ptr(gb), C.cast(arr, C.c_void_p), None, None, G, C.byref(cfg), _ptr(ws), ws.numel(),
                          _stream(x)), "gmp_bn_bwd")
     return g_u, gg, gb
 

@@ -75,6 +75,15 @@ int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int
                           const float* x, float* g_x, float* g_eps, int64_t num_nodes, int feat,
                           void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 
+/* Stacked-pass backward: g_x = (1+eps) g + sum over the transposed CSR of g (+ addend: the residual
+ * branch's gradient), rowdot[r] = <g[r,:], x[r,:]> (nullable) so that the eps gradient can be reduced
+ * per task with gmp_group_sum_1d: out[out_off_host[g]] = sum vals[rows[g] .. rows[g+1]). */
+int gmp_gin_aggregate_bwd_ex(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t, const float* eps,
+                             const float* x, const float* addend, float* g_x, float* rowdot, int64_t num_nodes,
+                             int feat, gmp_stream_t stream);
+int gmp_group_sum_1d(const float* vals, int groups, const int32_t* group_rows_host, const int64_t* out_off_host,
+                     float* out, gmp_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Generic segmented row sum:  out[r,:] (+)= scale_r * sum_{k in ptr[r]..ptr[r+1]} src[idx ? idx[k] : k, :]
  *   mean != 0  -> scale_r = 1 / max(ptr[r+1]-ptr[r], 1)   (PyG scatter 'mean')
@@ -121,6 +130,22 @@ int gmp_gemm_f32(int mode, const float* A, const float* B, const float* bias, fl
                  int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                  float alpha, int accumulate, int relu, void* workspace, size_t workspace_bytes,
                  gmp_stream_t stream);
+/* Grouped form: `groups` (<= 24) independent problems in ONE launch (blockIdx.z = group), row ranges
+ * group_rows_host[g] .. group_rows_host[g+1] (HOST int32, ascending):
+ *   NT / NN: group g multiplies ITS rows of A by ITS OWN weight matrix B + b_off_host[g] (+ bias +
+ *            bias_off_host[g]) into the same rows of C  -- the per-domain heads of one task
+ *            (pretrain_model.py:41-63) in one launch;
+ *   TN:      group g reduces over ITS rows of A [rows, M_tn] and B [rows, N] into C + c_off_host[g]
+ *            -- per-task weight gradients of the stacked backbone pass (one group per task, the
+ *            offsets point into the per-task gradient buffer PCGrad reads).
+ *            a_colsum (nullable): a_colsum + a_colsum_off_host[g] + m receives sum over the group's rows of
+ *            A[:, m] -- the bias gradient rides along with the weight gradient for free.
+ * Offsets are in floats; NULL offset arrays mean 0. */
+int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, const float* bias, float* C, int groups,
+                         const int32_t* group_rows_host, const int64_t* b_off_host, const int64_t* bias_off_host,
+                         const int64_t* c_off_host, float* a_colsum, const int64_t* a_colsum_off_host,
+                         int64_t M_tn, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha,
+                         int accumulate, int relu, gmp_stream_t stream);
 /* column sums: out[n] (+)= sum_m A[m,n]  (bias gradient), rows [0,M) */
 size_t gmp_colsum_workspace_bytes(int64_t M, int64_t N);
 int gmp_colsum(const float* A, float* out, int64_t M, int64_t N, int64_t lda, int accumulate,
@@ -151,20 +176,25 @@ typedef struct {
 } gmp_bn_config;
 
 size_t gmp_bn_workspace_bytes(int64_t rows, int channels, int num_segments, int64_t max_seg_rows);
-int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, int num_segments,
-               int64_t max_seg_rows, int64_t rows, int channels,
+/* seg_group: NULL, or device int32 [S] giving each segment's PARAMETER GROUP: gamma, beta and the running
+ * statistics are then [groups][C] arrays (the four per-domain input encoders stacked in one launch). */
+int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group,
+               int num_segments, int64_t max_seg_rows, int64_t rows, int channels,
                const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* save_mean, float* save_rstd, float* y,
                const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 /* backward: given g_y, the BN input u = x (+ residual, recomputed on the fly), saved stats.
  *   g_u [rows,C]   gradient w.r.t. the BN input (also the residual's gradient)
- *   g_gamma/g_beta [G,C] per parameter-group sums; group g covers segments
- *   grp_seg_ptr[g]..grp_seg_ptr[g+1] (host int32 [G+1]); G=1 -> ordinary gradients. */
-int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr, int num_segments,
-               int64_t max_seg_rows, int64_t rows, int channels,
+ *   g_gamma/g_beta: per GRADIENT group sums (<= 24 groups, one launch); group g covers segments
+ *   grp_seg_ptr_host[g]..[g+1] (host int32 [G+1]) and is written at g_gamma + grp_off_gamma_host[g]
+ *   (float offsets, host int64 [G]; NULL -> g*C).  G=1 -> ordinary gradients; G=#tasks with offsets
+ *   into the per-task gradient buffer -> the per-task gradients PCGrad needs, from ONE backward. */
+int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr,
+               const int32_t* seg_group, int num_segments, int64_t max_seg_rows, int64_t rows, int channels,
                const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                const float* save_mean, const float* save_rstd,
-               float* g_u, float* g_gamma, float* g_beta, const int32_t* grp_seg_ptr_host, int num_groups,
+               float* g_u, float* g_gamma, float* g_beta, const int32_t* grp_seg_ptr_host,
+               const int64_t* grp_off_gamma_host, const int64_t* grp_off_beta_host, int num_groups,
                const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
@@ -234,6 +264,48 @@ int gmp_cross_entropy_sum_bwd(const float* logits, const int64_t* target, int64_
                               const float* g_scale, float* g_logits, gmp_stream_t stream);
 int gmp_row_fill(float* dst, const int64_t* idx, const float* src, int64_t num_idx, int64_t num_dst_rows,
                  int feat, int broadcast, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one
+ * launch.  Features of all domains sit padded to `dpad` (<= 64) columns in x_all [R, dpad]; stacked row
+ * r reads x_all[src_row[r]]; segment s belongs to domain seg_dom[s] (weights at params + w_off_host[d],
+ * shape [256, d_in_host[d]], bias at params + b_off_host[d]); seg_colmask[s] bit k = feature k zeroed
+ * (attribute-mask augmentation, augmentations.py:17-29).  tiles [num_tiles][2] = (segment, first row),
+ * 32 rows each.  bwd: one gradient group per (task, domain) pair covering segments
+ * group_seg_host[g]..[g+1]; dW lands at grad_out + off_w_host[g] ([256, d_in]), db at + off_b_host[g].
+ * ------------------------------------------------------------------------- */
+int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+                    const uint64_t* seg_colmask, const int32_t* tiles, int num_tiles, const float* params,
+                    int num_domains, const int64_t* w_off_host, const int64_t* b_off_host,
+                    const int32_t* d_in_host, int dpad, float* z, gmp_stream_t stream);
+int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+                    const uint64_t* seg_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
+                    int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
+                    const int64_t* off_b_host, float* grad_out, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Multi-tensor PCGrad + clip_grad_norm_ + AdamW over flat buffers (gradient_surgery.py:41-103,
+ * pretrain.py:152-153, optimizers.py:8-75), five launches, deterministic.
+ *   task_grads [T][task_stride]: per-task gradients laid out like `params`; tensor k occupies
+ *   [tensor_off[k], +tensor_len[k]) (device arrays); has[k*8 + t] != 0 iff task t's backward produced a
+ *   gradient for tensor k (device uint8, row stride 8).
+ *   order_host[0..n_order): the shuffled task order of PCGrad (gradient_surgery.py:43).
+ *   last_task: last task in dict order -- where PCGrad emits nothing (tensor absent from the FIRST
+ *   shuffled task) the reference leaves that task's raw .grad in place (gradient_surgery.py:61 quirk);
+ *   extra_task: -1 or a task whose gradient is added on top (domain_adv, pretrain.py:149-150).
+ *   Tensors that end up without a gradient (flags_out[k] == 0) are skipped by AdamW entirely, including
+ *   their step count, as torch.optim does for grad=None.
+ *   apply_update == 0: stop after final_grad / normsq_out (unclipped) -- used by parity tests.
+ * ------------------------------------------------------------------------- */
+size_t gmp_mt_workspace_bytes(int num_tensors);
+int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
+                             const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
+                             const int32_t* order_host, int n_order, int last_task, int extra_task,
+                             float* params, float* exp_avg, float* exp_avg_sq, float* steps,
+                             const float* lr, const float* wd, float beta1, float beta2, float eps,
+                             float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
+                             int32_t* flags_out, void* workspace, size_t workspace_bytes, int apply_update,
+                             gmp_stream_t stream);
 
 #ifdef __cplusplus
 }
