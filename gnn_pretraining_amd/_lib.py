@@ -62,7 +62,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_segment_sum": (C.c_int, [p, p, p, p, i64, i32, i32, i32, p]),
     "gmp_row_gather": (C.c_int, [p, p, p, p, i64, i64, i32, p]),
     "gmp_segment_max_fwd": (C.c_int, [p, p, p, i64, i32, p]),
-    "gmp_segment_max_bwd": (C.c_int, [p, p, p, p, p, i64, i32, p]),
+    "gmp_segment_max_bwd": (C.c_int, [p, p, p, p, p, i64, i32, i32, p]),
     "gmp_gemm_f32_workspace_bytes": (sz, [i32, i64, i64, i64]),
     "gmp_gemm_f32": (C.c_int, [i32, p, p, p, p, i64, i64, i64, i64, i64, i64, f32, i32, i32, p, sz, p]),
     "gmp_gemm_f32_grouped": (C.c_int, [i32, p, p, p, p, i32, p, p, p, p, p, p, i64, i64, i64, i64, i64, i64, f32, i32, i32, p]),

@@ -3,7 +3,7 @@
 // its own (tiny) input width d_in in {7, 4, 37, 21}; features of all domains live padded to DPAD
 // columns in one resident matrix and a segment's rows are gathered through `src_row`, with the
 // attribute-mask augmentation (zeroed feature columns, augmentations.py:17-29) applied as a per-segment
-// column bitmask -- so augmented views never materialise their own feature matrices.
+// column bitmask per stacked row -- so augmented views never materialise their own feature matrices.
 // K <= 64 is far too small for MFMA tiles to pay: one thread per output column keeps its weight row in
 // registers and streams the rows of a 32-row tile from LDS.
 #include "gnnmp_internal.h"
@@ -20,7 +20,7 @@ struct EncArgs {
     const int* src_row;         // [N] row of x_all feeding stacked row r
     const int* seg_ptr;         // [S+1]
     const int* seg_dom;         // [S]
-    const unsigned long long* seg_colmask;   // [S] bit k set -> feature k zeroed (nullable)
+    const unsigned long long* row_colmask;   // [N] bit k set -> feature k of that stacked row zeroed (nullable)
     const int* tiles;           // [T][2] = (segment, first row)
     const float* params;        // flat parameter buffer
     int64_t w_off[MAXD], b_off[MAXD];
@@ -35,12 +35,14 @@ __global__ __launch_bounds__(H) void encoder_fwd_kernel(EncArgs a) {
     const int seg = a.tiles[2 * blockIdx.x], r0 = a.tiles[2 * blockIdx.x + 1];
     const int r1 = min(r0 + TR, a.seg_ptr[seg + 1]);
     const int dom = a.seg_dom[seg], din = a.d_in[dom];
-    const unsigned long long mask = a.seg_colmask ? a.seg_colmask[seg] : 0ull;
     const int c = threadIdx.x;
     for (int i = c; i < TR * DP; i += H) {
         const int rr = i / DP, k = i % DP;
         float v = 0.f;
-        if (r0 + rr < r1 && k < din && !((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+        if (r0 + rr < r1 && k < din) {
+            const unsigned long long mask = a.row_colmask ? a.row_colmask[r0 + rr] : 0ull;
+            if (!((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+        }
         xs[rr][k] = v;
     }
     float w[DP];
@@ -62,7 +64,7 @@ struct EncBwdArgs {
     const int* src_row;
     const int* seg_ptr;
     const int* seg_dom;
-    const unsigned long long* seg_colmask;
+    const unsigned long long* row_colmask;
     const float* gz;            // [N, 256]
     int dpad;
     int d_in[MAXD];
@@ -84,14 +86,16 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
     for (int seg = a.gseg[g]; seg < a.gseg[g + 1]; ++seg) {
         const int dom = a.seg_dom[seg];
         din = a.d_in[dom];
-        const unsigned long long mask = a.seg_colmask ? a.seg_colmask[seg] : 0ull;
         for (int r0 = a.seg_ptr[seg]; r0 < a.seg_ptr[seg + 1]; r0 += TR) {
             const int r1 = min(r0 + TR, a.seg_ptr[seg + 1]);
             __syncthreads();
             for (int i = c; i < TR * DP; i += H) {
                 const int rr = i / DP, k = i % DP;
                 float v = 0.f;
-                if (r0 + rr < r1 && k < din && !((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+                if (r0 + rr < r1 && k < din) {
+                    const unsigned long long mask = a.row_colmask ? a.row_colmask[r0 + rr] : 0ull;
+                    if (!((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+                }
                 xs[rr][k] = v;
             }
             __syncthreads();
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
 }  // namespace
 
 extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
-                               const uint64_t* seg_colmask, const int32_t* tiles, int num_tiles, const float* params,
+                               const uint64_t* row_colmask, const int32_t* tiles, int num_tiles, const float* params,
                                int num_domains, const int64_t* w_off_host, const int64_t* b_off_host,
                                const int32_t* d_in_host, int dpad, float* z, gmp_stream_t stream) {
     if (num_tiles < 0 || num_domains < 1 || num_domains > MAXD || dpad < 1 || dpad > DPAD_MAX)
@@ -125,7 +129,7 @@ extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const
         return gmp::fail(GMP_ERR_ARG, "encoder_fwd: null pointer");
     EncArgs a{};
     a.x_all = x_all; a.src_row = src_row; a.seg_ptr = seg_ptr; a.seg_dom = seg_dom;
-    a.seg_colmask = (const unsigned long long*)seg_colmask; a.tiles = tiles; a.params = params; a.dpad = dpad; a.z = z;
+    a.row_colmask = (const unsigned long long*)row_colmask; a.tiles = tiles; a.params = params; a.dpad = dpad; a.z = z;
     for (int d = 0; d < num_domains; ++d) {
         a.w_off[d] = w_off_host[d]; a.b_off[d] = b_off_host[d]; a.d_in[d] = d_in_host[d];
         if (a.d_in[d] < 1 || a.d_in[d] > dpad) return gmp::fail(GMP_ERR_ARG, "encoder_fwd: d_in[%d]=%d exceeds dpad %d", d, a.d_in[d], dpad);
@@ -139,7 +143,7 @@ extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const
 }
 
 extern "C" int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
-                               const uint64_t* seg_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
+                               const uint64_t* row_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
                                int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
                                const int64_t* off_b_host, float* grad_out, gmp_stream_t stream) {
     if (groups < 0 || groups > GMP_MAX_GROUPS || num_domains < 1 || num_domains > MAXD || dpad < 1 || dpad > DPAD_MAX)
@@ -149,7 +153,7 @@ extern "C" int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const
         return gmp::fail(GMP_ERR_ARG, "encoder_bwd: null pointer");
     EncBwdArgs a{};
     a.x_all = x_all; a.src_row = src_row; a.seg_ptr = seg_ptr; a.seg_dom = seg_dom;
-    a.seg_colmask = (const unsigned long long*)seg_colmask; a.gz = g_z; a.dpad = dpad; a.groups = groups; a.out = grad_out;
+    a.row_colmask = (const unsigned long long*)row_colmask; a.gz = g_z; a.dpad = dpad; a.groups = groups; a.out = grad_out;
     for (int d = 0; d < num_domains; ++d) a.d_in[d] = d_in_host[d];
     for (int g = 0; g <= groups; ++g) a.gseg[g] = group_seg_host[g];
     for (int g = 0; g < groups; ++g) { a.off_w[g] = off_w_host[g]; a.off_b[g] = off_b_host[g]; }

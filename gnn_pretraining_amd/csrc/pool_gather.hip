@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __rest
 // whole columns are 0, so this matters: such a column gets g / (n + 1), not g / n.
 __global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
                                                             const float4* __restrict__ mx, const int* __restrict__ ptr,
-                                                            float4* __restrict__ gx, int64_t B, int F4) {
+                                                            float4* __restrict__ gx, int64_t B, int F4, int accumulate) {
     const int lane = threadIdx.x % GMP_WAVE;
     for (int64_t b = wave_id(); b < B; b += wave_count()) {
         const int s = ptr[b], e = ptr[b + 1];
@@ -89,8 +89,12 @@ __global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __rest
             const float4 q = make_float4(gg.x / n.x, gg.y / n.y, gg.z / n.z, gg.w / n.w);
             for (int r = s; r < e; ++r) {
                 float4 v = x[(int64_t)r * F4 + c];
-                gx[(int64_t)r * F4 + c] = make_float4(v.x == m.x ? q.x : 0.f, v.y == m.y ? q.y : 0.f,
-                                                      v.z == m.z ? q.z : 0.f, v.w == m.w ? q.w : 0.f);
+                float4 o = make_float4(v.x == m.x ? q.x : 0.f, v.y == m.y ? q.y : 0.f, v.z == m.z ? q.z : 0.f, v.w == m.w ? q.w : 0.f);
+                if (accumulate) {
+                    const float4 p = gx[(int64_t)r * F4 + c];
+                    o = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+                }
+                gx[(int64_t)r * F4 + c] = o;
             }
         }
     }
@@ -174,12 +178,12 @@ extern "C" int gmp_segment_max_fwd(const float* x, const int32_t* ptr, float* ou
 }
 
 extern "C" int gmp_segment_max_bwd(const float* g_out, const float* x, const float* out, const int32_t* ptr, float* g_x,
-                                   int64_t B, int feat, gmp_stream_t stream) {
+                                   int64_t B, int feat, int accumulate, gmp_stream_t stream) {
     if (int rc = feat_ok("segment_max_bwd", feat)) return rc;
     if (B < 0 || (B > 0 && (!g_out || !x || !out || !ptr || !g_x))) return gmp::fail(GMP_ERR_ARG, "segment_max_bwd: bad argument");
     if (B == 0) return GMP_OK;
     hipLaunchKernelGGL(seg_max_bwd_kernel, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)g_out,
-                       (const float4*)x, (const float4*)out, ptr, (float4*)g_x, B, feat / 4);
+                       (const float4*)x, (const float4*)out, ptr, (float4*)g_x, B, feat / 4, accumulate);
     return gmp::check_launch("seg_max_bwd_kernel");
 }
 

@@ -1,0 +1,832 @@
+"""Stacked-step engine: one whole pre-training step (all tasks x all domains) as ~250 launches.
+
+The reference runs 28 separate encoder+backbone forwards per s4 step (7 per domain: NFM 1, LP 1, NC 2,
+GC 2, GP 1 -- src/pretrain/pretrain.py:124-129 over tasks.py), then 5 full backwards for PCGrad.
+All 28 share the backbone weights, so here they are STACKED into one block-diagonal pass:
+
+  * every reference forward() call becomes a *segment* of rows; BatchNorm statistics are taken per
+    segment (gmp_bn_fwd seg_ptr), so the stacked pass computes exactly what the 28 calls compute,
+    running statistics included (segments are applied in the reference's call order);
+  * segments are laid out task-major, so each task owns one contiguous row range: ONE backward pass
+    produces all per-task weight gradients PCGrad needs (grouped TN GEMMs / grouped reductions that
+    write straight into a [tasks, params] gradient buffer) instead of five backward passes;
+  * per-domain heads run as grouped GEMMs (one group per domain);
+  * PCGrad + clip + AdamW are five multi-tensor launches over flat buffers, with the reference's
+    "which tensors receive a gradient" rule (gradient_surgery.py:61) reproduced exactly.
+
+Host work per step is index bookkeeping only (augmentation / masks / negatives with the reference's CPU
+RNG contract) and ships to the device in two packed copies; nothing in the step reads back from the GPU.
+No autograd: forward and backward are explicit kernel sequences over a preallocated arena.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from .constants import DOMAIN_DIMENSIONS, GRAPH_PROPERTY_DIM
+from .graph import Batch
+from .models.gnn import DROPOUT_RATE, GNN_HIDDEN_DIM, GNN_NUM_LAYERS
+from .models.pretrain_model import PretrainableGNN, draw_mask_indices
+from .pretrain.augmentations import GraphAugmentor, _augment_one, common_masks
+from .pretrain.control import DEFAULT_LR, DEFAULT_WEIGHT_DECAY, TASK_SPECIFIC_LR
+from .pretrain.tasks import sample_negative_edges
+
+H = GNN_HIDDEN_DIM
+NT, NN, TN = 0, 1, 2
+MAXT = 8
+SUPPORTED_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop")
+
+
+def _i32(xs) -> "C.Array":
+    return (C.c_int32 * len(xs))(*[int(v) for v in xs])
+
+
+def _i64(xs) -> "C.Array":
+    return (C.c_int64 * len(xs))(*[int(v) for v in xs])
+
+
+class StepInputs:
+    """Device-resident input of one step (the benchmark keeps a pool of these in HBM):
+    all domains' features padded into one matrix + per-domain offsets, plus host twins for index work."""
+
+    def __init__(self, batches: Dict[str, Batch], device, dpad: int) -> None:
+        self.domains = list(batches)
+        self.host = {d: b.host() for d, b in batches.items()}
+        rows, self.row_off = 0, {}
+        for d in self.domains:
+            self.row_off[d] = rows
+            rows += self.host[d].num_nodes
+        x = torch.zeros(rows, dpad)
+        gp = []
+        for d in self.domains:
+            hb = self.host[d]
+            x[self.row_off[d]:self.row_off[d] + hb.num_nodes, :hb.x.size(1)] = hb.x
+            gp.append(hb.graph_properties.to(torch.float32).view(hb.num_graphs, GRAPH_PROPERTY_DIM))
+        self.x_all = x.to(device)
+        self.graph_props = torch.cat(gp).to(device)           # [sum B, 12] in domain order
+
+
+class StepPlan:
+    """Host-side description of one stacked step (pure index data)."""
+    pass
+
+
+class StepEngine:
+    def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
+                 max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
+                 grad_sync=None) -> None:
+        for t in tasks:
+            if t not in SUPPORTED_TASKS:
+                raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
+        self.model, self.tasks, self.domains, self.device = model, list(tasks), list(domains), torch.device(device)
+        self.T, self.D = len(self.tasks), len(self.domains)
+        self.lib = L.lib()
+        self.dpad = 40 if max(DOMAIN_DIMENSIONS[d] for d in domains) <= 40 else 64
+        self.max_rows, self.max_edges = max_rows, max_edges
+        self.seed, self.step_count = seed, 0
+        self.shuffle_rng = shuffle_rng
+        self.grad_sync = grad_sync
+        self.temperature = 0.5
+        self.dropout_p = DROPOUT_RATE
+        self.max_grad_norm = 0.5
+        self._flatten_parameters()
+        self._build_tables()
+        self._alloc()
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten_parameters(self) -> None:
+        m, dev = self.model, self.device
+        named = dict(m.named_parameters())
+        enc = [m.input_encoders[d] for d in self.domains]
+        order: List[Tuple[str, Tensor]] = []
+        for d, e in zip(self.domains, enc):
+            order.append((f"input_encoders.{d}.linear.weight", e.linear.weight))
+        for key in ("linear.bias", "batch_norm.weight", "batch_norm.bias"):      # [D][256] blocks (grouped BN layout)
+            for d in self.domains:
+                order.append((f"input_encoders.{d}.{key}", named[f"input_encoders.{d}.{key}"]))
+        seen = {n for n, _ in order}
+        for n, p in named.items():
+            if n not in seen:
+                order.append((n, p))
+        al4 = lambda v: (v + 3) // 4 * 4           # every tensor starts 16-byte aligned (float4 / MFMA tile loads)
+        self.off: Dict[str, int] = {}
+        o = 0
+        for n, p in order:
+            self.off[n] = o
+            o += al4(p.numel())
+        self.P = o
+        self.P_shared = min(self.off[n] for n, _ in order if n.startswith("heads.")) if any(n.startswith("heads.") for n, _ in order) else o
+        self.flat = torch.zeros(self.P, device=dev)
+        for n, p in order:
+            o = self.off[n]
+            self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + p.numel()].view_as(p)
+        self.names = [n for n, _ in order]
+        self.numel = {n: p.numel() for n, p in order}
+        # encoder running statistics as [D][256] blocks
+        self.enc_rm = torch.zeros(self.D, H, device=dev)
+        self.enc_rv = torch.ones(self.D, H, device=dev)
+        for i, e in enumerate(enc):
+            self.enc_rm[i].copy_(e.batch_norm.running_mean)
+            self.enc_rv[i].copy_(e.batch_norm.running_var)
+            e.batch_norm.running_mean.data = self.enc_rm[i]
+            e.batch_norm.running_var.data = self.enc_rv[i]
+        self.exp_avg = torch.zeros(self.P, device=dev)
+        self.exp_avg_sq = torch.zeros(self.P, device=dev)
+
+    def _build_tables(self) -> None:
+        dev, T = self.device, self.T
+        K = len(self.names)
+        self.K = K
+        self.t_off = torch.tensor([self.off[n] for n in self.names], dtype=torch.int64, device=dev)
+        self.t_len = torch.tensor([self.numel[n] for n in self.names], dtype=torch.int32, device=dev)
+        has = np.zeros((K, MAXT), dtype=np.uint8)
+        lr = np.zeros(K, dtype=np.float32)
+        for k, n in enumerate(self.names):
+            lr[k] = DEFAULT_LR
+            if n.startswith("input_encoders."):
+                for t, task in enumerate(self.tasks):
+                    has[k, t] = task != "node_feat_mask"        # NFM runs the encoder under no_grad
+            elif n == "mask_token":
+                for t, task in enumerate(self.tasks):
+                    has[k, t] = task == "node_feat_mask"
+            elif n.startswith("gnn_backbone."):
+                has[k, :T] = 1
+            elif n.startswith("heads."):
+                for t, task in enumerate(self.tasks):
+                    if f"heads.{task}" in n:
+                        has[k, t] = 1
+                        lr[k] = TASK_SPECIFIC_LR[task]
+        self.has_static = has
+        self.has = torch.from_numpy(has.copy()).to(dev)
+        self.lr = torch.from_numpy(lr).to(dev)
+        self.wd = torch.full((K,), DEFAULT_WEIGHT_DECAY, dtype=torch.float32, device=dev)
+        self.steps = torch.zeros(K, dtype=torch.float32, device=dev)
+        self.name_index = {n: k for k, n in enumerate(self.names)}
+
+    def _alloc(self) -> None:
+        dev, R = self.device, self.max_rows
+        f = lambda *shape: torch.empty(*shape, device=dev)
+        self.task_grads = torch.zeros(self.T, self.P, device=dev)
+        self.final_grad = torch.zeros(self.P, device=dev)
+        self.normsq = torch.zeros(1, device=dev)
+        self.metrics = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(self.K, dtype=torch.int32, device=dev)
+        self.mt_ws = torch.empty(self.lib.gmp_mt_workspace_bytes(self.K), dtype=torch.uint8, device=dev)
+        Lr = GNN_NUM_LAYERS
+        self.z0 = f(R, H)
+        self.h = [f(R, H) for _ in range(Lr + 1)]
+        self.a = [f(R, H) for _ in range(Lr)]
+        self.z1 = [f(R, 2 * H) for _ in range(Lr)]
+        self.r1 = [f(R, 2 * H) for _ in range(Lr)]
+        self.z2 = [f(R, H) for _ in range(Lr)]
+        self.S_MAX = 64
+        self.stat = {k: f(Lr, self.S_MAX, c) for k, c in (("m1", 2 * H), ("s1", 2 * H), ("m2", H), ("s2", H))}
+        self.enc_mean, self.enc_rstd = f(self.S_MAX, H), f(self.S_MAX, H)
+        self.gA, self.gB = f(R, H), f(R, H)                  # ping-pong [R,256] gradients
+        self.gW = f(R, 2 * H)                                # [R,512] gradients
+        self.gW2 = f(R, 2 * H)
+        self.rowdot = f(R)
+        self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(R, 2 * H, self.S_MAX, 512), dtype=torch.uint8, device=dev)
+        self.csr_ws = torch.empty(self.lib.gmp_csr_build_workspace_bytes(R, self.max_edges), dtype=torch.uint8, device=dev)
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        self.csr = [i32(R + 1), i32(self.max_edges), i32(self.max_edges), i32(R + 1), i32(self.max_edges), i32(self.max_edges)]
+        self.csr_status = i32(1)
+        self.lp_csr = [i32(R + 1), i32(self.max_edges), i32(self.max_edges), i32(R + 1), i32(self.max_edges), i32(self.max_edges)]
+        self.loss_sums = torch.zeros(MAXT, device=dev)       # per-task loss SUMS of the last step
+        self.loss_ws = torch.empty(self.lib.gmp_loss_workspace_bytes(R * H), dtype=torch.uint8, device=dev)
+        # head workspaces (rows bounded by max_rows / edges)
+        self.KMAX = self.max_edges
+        self.hd = {k: f(n, c) for k, (n, c) in {
+            "nfm_in": (R, H), "nfm_y1": (R, H), "nfm_d1": (R, H), "nfm_y2": (R, H), "nfm_tgt": (R, H), "nfm_g": (R, H), "nfm_g1": (R, H),
+            "lp_feat": (self.KMAX, 3 * H), "lp_y1": (self.KMAX, H), "lp_d1": (self.KMAX, H), "lp_gy1": (self.KMAX, H),
+            "lp_gfeat": (self.KMAX, 3 * H), "lp_ghs": (self.KMAX, H), "lp_ghd": (self.KMAX, H),
+            "nc_in": (2 * R, H), "nc_y1": (2 * R, H), "nc_d1": (2 * R, H), "nc_z": (2 * R, 128), "nc_gz": (2 * R, 128), "nc_g1": (2 * R, H), "nc_gin": (2 * R, H),
+            "gc_mean": (1024, H), "gc_max": (1024, H), "gc_in": (1024, 2 * H), "gc_y1": (1024, H), "gc_d1": (1024, H), "gc_z": (1024, 128),
+            "gc_gz": (1024, 128), "gc_g1": (1024, H), "gc_gin": (1024, 2 * H), "gc_gmean": (1024, H), "gc_gmax": (1024, H),
+            "gp_in": (1024, H), "gp_y1": (1024, 2 * H), "gp_d1": (1024, 2 * H), "gp_y2": (1024, 16), "gp_g2": (1024, 16), "gp_g1": (1024, 2 * H), "gp_gin": (1024, H),
+        }.items()}
+        self.lp_y2, self.lp_p, self.lp_lab, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)
+        self.gp_y2 = f(1024, GRAPH_PROPERTY_DIM)
+        self.gp_g2 = f(1024, GRAPH_PROPERTY_DIM)
+        self.ntx_ws = [torch.empty(self.lib.gmp_nt_xent_workspace_bytes(2048, 128), dtype=torch.uint8, device=dev) for _ in range(2 * self.D)]
+        self.scal = torch.zeros(64, device=dev)              # device scalars: 1/size per task, NT-Xent losses ...
+        # packed per-step index uploads (pinned staging)
+        self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536, 4 * self.max_edges + 8 * R
+        self.pin32 = torch.empty(self.i32_cap, dtype=torch.int32).pin_memory()
+        self.pin64 = torch.empty(self.i64_cap, dtype=torch.int64).pin_memory()
+        self.dev32 = torch.empty(self.i32_cap, dtype=torch.int32, device=dev)
+        self.dev64 = torch.empty(self.i64_cap, dtype=torch.int64, device=dev)
+        self.pinf = torch.empty(64, dtype=torch.float32).pin_memory()
+
+    # ------------------------------------------------------------------ host: plan one step
+    def draw(self, inp: StepInputs, gen: torch.Generator) -> Dict[str, object]:
+        """All RNG of one step, in the reference's order (tasks in ACTIVE_TASKS order, domains in dict order)."""
+        art: Dict[str, object] = {}
+        host = {d: inp.host[d] for d in self.domains}
+        for t in self.tasks:
+            if t == "node_feat_mask":
+                art[t] = {d: draw_mask_indices(b.ptr_host, gen) for d, b in host.items()}
+            elif t == "link_pred":
+                art[t] = {d: sample_negative_edges(b, gen) for d, b in host.items()}
+            elif t in ("node_contrast", "graph_contrast"):
+                art[t] = {d: (self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
+                          for d, b in host.items()}
+        return art
+
+    @staticmethod
+    def _draw_views(b: Batch, gen: torch.Generator):
+        """Same draws as GraphAugmentor.create_two_views, kept as index arrays (no feature copies)."""
+        ei = b.edge_index.numpy()
+        F = b.x.size(1)
+        out = []
+        for g in range(b.num_graphs):
+            s, e = b.ptr_host[g], b.ptr_host[g + 1]
+            es, ee = b.edge_ptr_host[g], b.edge_ptr_host[g + 1]
+            loc = ei[:, es:ee] - s
+            v1 = _augment_one(e - s, loc, F, gen)
+            v2 = _augment_one(e - s, loc, F, gen)
+            out.append((v1, v2))
+        return out
+
+    def plan(self, inp: StepInputs, art: Dict[str, object]) -> StepPlan:
+        p = StepPlan()
+        D = self.domains
+        seg_ptr, seg_dom, seg_task, seg_mask = [0], [], [], []
+        src_rows: List[np.ndarray] = []
+        edges: List[np.ndarray] = []
+        task_row = [0]
+        p.info = {}
+
+        def add_segment(task_i: int, dom_i: int, rows: np.ndarray, e_local: np.ndarray, colmask: int = 0) -> int:
+            r0 = seg_ptr[-1]
+            src_rows.append(rows.astype(np.int32))
+            edges.append(e_local.astype(np.int64) + r0)
+            seg_ptr.append(r0 + len(rows)); seg_dom.append(dom_i); seg_task.append(task_i); seg_mask.append(colmask)
+            return r0
+
+        def view_mask(v) -> int:
+            m = 0
+            if v.masked_cols is not None:
+                for c in v.masked_cols:
+                    m |= 1 << int(c)
+            return m
+
+        for ti, t in enumerate(self.tasks):
+            info = p.info[t] = {}
+            for di, d in enumerate(D):
+                hb, roff = inp.host[d], inp.row_off[d]
+                base_rows = np.arange(roff, roff + hb.num_nodes)
+                if t in ("node_feat_mask", "link_pred", "graph_prop"):
+                    r0 = add_segment(ti, di, base_rows, hb.edge_index.numpy())
+                    info[d] = {"r0": r0, "n": hb.num_nodes, "ptr": [r0 + v for v in hb.ptr_host]}
+                else:
+                    views = art[t][d]
+                    if views is None:
+                        info[d] = None
+                        continue
+                    per_view = []
+                    for vi in (0, 1):
+                        n_acc, rows, eds, ptr, commons = 0, [], [], [0], []
+                        for g, pair in enumerate(views):
+                            v = pair[vi]
+                            rows.append(v.kept + roff + hb.ptr_host[g])
+                            eds.append(v.edges + n_acc)
+                            other = pair[1 - vi]
+                            commons.append(np.flatnonzero(np.isin(v.kept, other.kept)) + n_acc)
+                            n_acc += len(v.kept)
+                            ptr.append(n_acc)
+                        # one column mask per SEGMENT is not enough: the attribute mask is per graph -> split
+                        # a view into runs of graphs with the same mask (almost always a single run)
+                        masks = [view_mask(pair[vi]) for pair in views]
+                        per_view.append((np.concatenate(rows), np.concatenate(eds, axis=1), ptr, np.concatenate(commons), masks))
+                    info[d] = {"views": []}
+                    for rows, eds, ptr, common, masks in per_view:
+                        r0 = add_segment(ti, di, rows, eds, 0)
+                        info[d]["views"].append({"r0": r0, "n": len(rows), "ptr": [r0 + v for v in ptr], "common": common + r0,
+                                                 "graph_masks": masks})
+            task_row.append(seg_ptr[-1])
+        p.seg_ptr, p.seg_dom, p.seg_task, p.task_row = seg_ptr, seg_dom, seg_task, task_row
+        p.N = seg_ptr[-1]
+        p.S = len(seg_dom)
+        p.src_row = np.concatenate(src_rows)
+        p.edge_index = np.concatenate(edges, axis=1)
+        p.E = p.edge_index.shape[1]
+        p.max_seg = max(b - a for a, b in zip(seg_ptr[:-1], seg_ptr[1:]))
+        # per-row attribute masks: rows whose graph drew an attribute mask get their own feature bitmask
+        rowmask = np.zeros(p.N, dtype=np.uint64)
+        any_mask = False
+        for t in self.tasks:
+            if t not in ("node_contrast", "graph_contrast"):
+                continue
+            for d in D:
+                inf = p.info[t][d]
+                if inf is None:
+                    continue
+                for v in inf["views"]:
+                    for g, m in enumerate(v["graph_masks"]):
+                        if m:
+                            rowmask[v["ptr"][g]:v["ptr"][g + 1]] = np.uint64(m)
+                            any_mask = True
+        p.rowmask = rowmask if any_mask else None
+        if p.N > self.max_rows or p.E > self.max_edges or p.S > self.S_MAX:
+            raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
+                               f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
+        return p
+
+    # ------------------------------------------------------------------ device helpers
+    def _st(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _chk(self, rc: int, what: str) -> None:
+        if rc:
+            L.check(rc, what)
+
+    def _gemm(self, mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, relu=False, accumulate=False):
+        self._chk(self.lib.gmp_gemm_f32(mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, 1.0, int(accumulate), int(relu), None, 0, self._st()), "gemm")
+
+    def _gemm_g(self, mode, A, B, bias, Cc, rows, boff, biasoff, coff, asum, asumoff, M_tn, N, K, lda, ldb, ldc, relu=False):
+        G = len(rows) - 1
+        self._chk(self.lib.gmp_gemm_f32_grouped(mode, A, B, bias, Cc, G, _i32(rows), None if boff is None else _i64(boff),
+                                                None if biasoff is None else _i64(biasoff), None if coff is None else _i64(coff),
+                                                asum, None if asumoff is None else _i64(asumoff), M_tn, N, K, lda, ldb, ldc, 1.0, 0,
+                                                int(relu), self._st()), "gemm_grouped")
+
+    def _bn_cfg(self, relu: bool, dropout: bool, site: int) -> L.BnConfig:
+        p = self.dropout_p if (dropout and self.model.training) else 0.0
+        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site)
+
+    # ------------------------------------------------------------------ one step
+    def step(self, inp: StepInputs, gen: torch.Generator, art: Optional[Dict[str, object]] = None,
+             order: Optional[List[str]] = None, apply_update: bool = True) -> None:
+        """Forward, backward, PCGrad, clip, AdamW for one step.  Nothing is read back: losses stay in
+        self.loss_sums / self.plan_sizes until someone asks (losses())."""
+        if art is None:
+            art = self.draw(inp, gen)
+        p = self.plan(inp, art)
+        self._upload(p, inp, art)
+        self._forward(p, inp)
+        self._heads_and_backward(p, inp)
+        self._optimizer(p, order, apply_update)
+        self.step_count += 1
+        self.last_plan = p
+
+    # ---- upload ------------------------------------------------------------------------------------
+    def _upload(self, p: StepPlan, inp: StepInputs, art) -> None:
+        lay32, lay64 = {}, {}
+        cur = {"o32": 0, "o64": 0}
+
+        def put32(name: str, arr) -> None:
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.int32).reshape(-1))
+            o = cur["o32"]
+            if o + a.size > self.i32_cap:
+                raise L.GnnmpError("engine: int32 staging buffer too small")
+            self.pin32[o:o + a.size] = torch.from_numpy(a)
+            lay32[name] = o
+            cur["o32"] = o + (a.size + 3) // 4 * 4
+
+        def put64(name: str, arr) -> None:
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.int64).reshape(-1))
+            o = cur["o64"]
+            if o + a.size > self.i64_cap:
+                raise L.GnnmpError("engine: int64 staging buffer too small")
+            self.pin64[o:o + a.size] = torch.from_numpy(a)
+            lay64[name] = o
+            cur["o64"] = o + (a.size + 1) // 2 * 2
+
+        put32("seg_ptr", p.seg_ptr); put32("seg_dom", p.seg_dom); put32("src_row", p.src_row)
+        tiles = [(s, r) for s in range(p.S) for r in range(p.seg_ptr[s], p.seg_ptr[s + 1], 32)]
+        p.num_tiles = len(tiles)
+        put32("tiles", tiles)
+        put64("edge_index", p.edge_index)
+        if p.rowmask is not None:
+            put64("rowmask", p.rowmask.view(np.int64))
+        sizes, D = {}, self.domains
+        p.skipped = []                       # (task index, domain) pairs that contribute nothing this step
+        for ti, t in enumerate(self.tasks):
+            info = p.info[t]
+            if t == "node_feat_mask":
+                idx, rows = [], [0]
+                for d in D:
+                    idx.append(art[t][d].numpy() + info[d]["r0"])
+                    rows.append(rows[-1] + len(idx[-1]))
+                    if len(idx[-1]) == 0:
+                        p.skipped.append((ti, d))
+                put64("nfm_idx", np.concatenate(idx))
+                p.nfm_rows = rows
+                sizes[t] = rows[-1] * H
+            elif t == "link_pred":
+                eds, ks, npos = [], [0], []
+                for d in D:
+                    pos = inp.host[d].edge_index.numpy() + info[d]["r0"]
+                    neg = art[t][d].numpy() + info[d]["r0"]
+                    eds.append(np.concatenate([pos, neg], axis=1))
+                    ks.append(ks[-1] + eds[-1].shape[1]); npos.append(pos.shape[1])
+                e = np.concatenate(eds, axis=1)
+                if e.shape[1] > self.KMAX:
+                    raise L.GnnmpError("engine: too many link-prediction edges")
+                put64("lp_edges", e)
+                lab = np.zeros(e.shape[1], dtype=np.float32)
+                for i in range(len(D)):
+                    lab[ks[i]:ks[i] + npos[i]] = 1.0
+                p.lp_labels, p.lp_K = lab, e.shape[1]
+                sizes[t] = e.shape[1]
+            elif t == "node_contrast":
+                idx, rows, ns = [], [0], []
+                for d in D:
+                    c1, c2 = info[d]["views"][0]["common"], info[d]["views"][1]["common"]
+                    n = len(c1) if (len(c1) >= 2 and len(c2) >= 2) else 0       # tasks.py:171-173
+                    ns.append(n)
+                    if n:
+                        idx += [c1, c2]
+                    else:
+                        p.skipped.append((ti, d))
+                    rows.append(rows[-1] + 2 * n)
+                put64("nc_idx", np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64))
+                p.nc_rows, p.nc_n = rows, ns
+                sizes[t] = rows[-1]
+            elif t == "graph_contrast":
+                starts, rows, ns = [], [0], []
+                for d in D:
+                    inf = info[d]
+                    if inf is None:
+                        ns.append(0); rows.append(rows[-1]); p.skipped.append((ti, d))
+                        continue
+                    for v in inf["views"]:
+                        starts += v["ptr"][:-1]
+                    B = len(inf["views"][0]["ptr"]) - 1
+                    ns.append(B); rows.append(rows[-1] + 2 * B)
+                ptr = np.asarray(starts + [p.task_row[ti + 1]], dtype=np.int64)
+                put32("gc_ptr", ptr)
+                put64("gc_gid", np.repeat(np.arange(len(starts)), np.diff(ptr)))
+                p.gc_rows, p.gc_n, p.gc_B, p.gc_r0, p.gc_M = rows, ns, len(starts), p.task_row[ti], p.task_row[ti + 1] - p.task_row[ti]
+                sizes[t] = rows[-1]
+            elif t == "graph_prop":
+                starts, rows = [], [0]
+                for d in D:
+                    pr = info[d]["ptr"]
+                    starts += pr[:-1]
+                    rows.append(rows[-1] + len(pr) - 1)
+                ptr = np.asarray(starts + [p.task_row[ti + 1]], dtype=np.int64)
+                put32("gp_ptr", ptr)
+                put64("gp_gid", np.repeat(np.arange(len(starts)), np.diff(ptr)))
+                p.gp_rows, p.gp_B, p.gp_r0, p.gp_M = rows, len(starts), p.task_row[ti], p.task_row[ti + 1] - p.task_row[ti]
+                sizes[t] = rows[-1] * GRAPH_PROPERTY_DIM
+        p.sizes = sizes
+        o32, o64 = cur["o32"], cur["o64"]
+        self.dev32[:o32].copy_(self.pin32[:o32], non_blocking=True)
+        self.dev64[:o64].copy_(self.pin64[:o64], non_blocking=True)
+        self.pinf.zero_()
+        for ti, t in enumerate(self.tasks):
+            self.pinf[ti] = 1.0 / max(sizes[t], 1)
+        self.scal.copy_(self.pinf, non_blocking=True)          # [0:8) = 1/size per task, [16:48) = per-domain NT-Xent sums (zeroed)
+        if "link_pred" in self.tasks:
+            self.lp_lab[:p.lp_K].copy_(torch.from_numpy(p.lp_labels), non_blocking=True)
+        b32, b64 = self.dev32.data_ptr(), self.dev64.data_ptr()
+        p.d32 = {k: b32 + 4 * o for k, o in lay32.items()}
+        p.d64 = {k: b64 + 8 * o for k, o in lay64.items()}
+        # per-step gradient-availability table (static unless a (task, domain) pair dropped out)
+        if p.skipped:
+            has = self.has_static.copy()
+            for ti, d in p.skipped:
+                t = self.tasks[ti]
+                k = [self.name_index[n] for n in self.names if n.startswith(f"heads.{t}.{d}.")]
+                has[k, ti] = 0
+            self.has.copy_(torch.from_numpy(has).to(self.device))
+            self._has_dirty = True
+        elif getattr(self, "_has_dirty", False):
+            self.has.copy_(torch.from_numpy(self.has_static).to(self.device))
+            self._has_dirty = False
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _P(self, name: str) -> int:
+        return self.flat.data_ptr() + 4 * self.off[name]
+
+    def _TG(self, t: int, name: str) -> int:
+        """Float offset of (task t, tensor) inside the [T, P] per-task gradient buffer."""
+        return t * self.P + self.off[name]
+
+    def _forward(self, p: StepPlan, inp: StepInputs) -> None:
+        lib, st, N, D, P = self.lib, self._st(), p.N, self.domains, self._P
+        c = self.csr
+        self._chk(lib.gmp_csr_build(p.d64["edge_index"], N, p.E, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                                    c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(),
+                                    self.csr_ws.numel(), st), "csr_build")
+        w_off = [self.off[f"input_encoders.{d}.linear.weight"] for d in D]
+        b_off = [self.off[f"input_encoders.{d}.linear.bias"] for d in D]
+        d_in = [DOMAIN_DIMENSIONS[d] for d in D]
+        self._chk(lib.gmp_encoder_fwd(inp.x_all.data_ptr(), p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
+                                      p.d32["tiles"], p.num_tiles, self.flat.data_ptr(), len(D), _i64(w_off), _i64(b_off), _i32(d_in),
+                                      self.dpad, self.z0.data_ptr(), st), "encoder_fwd")
+        cfg = self._bn_cfg(True, True, 1)
+        e0 = f"input_encoders.{D[0]}."
+        self._chk(lib.gmp_bn_fwd(self.z0.data_ptr(), None, p.d32["seg_ptr"], p.d32["seg_dom"], p.S, p.max_seg, N, H,
+                                 P(e0 + "batch_norm.weight"), P(e0 + "batch_norm.bias"), self.enc_rm.data_ptr(), self.enc_rv.data_ptr(),
+                                 self.enc_mean.data_ptr(), self.enc_rstd.data_ptr(), self.h[0].data_ptr(), C.byref(cfg),
+                                 self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn_fwd encoders")
+        if "node_feat_mask" in self.tasks and p.nfm_rows[-1]:
+            M = p.nfm_rows[-1]
+            self._chk(lib.gmp_row_gather(self.h[0].data_ptr(), p.d64["nfm_idx"], None, self.hd["nfm_tgt"].data_ptr(), M, N, H, st), "nfm target")
+            self._chk(lib.gmp_row_fill(self.h[0].data_ptr(), p.d64["nfm_idx"], P("mask_token"), M, N, H, 1, st), "nfm mask")
+        for l in range(GNN_NUM_LAYERS):
+            pre = f"gnn_backbone.layers.{l}."
+            layer = self.model.gnn_backbone.layers[l]
+            self._chk(lib.gmp_gin_aggregate_fwd(self.h[l].data_ptr(), c[0].data_ptr(), c[1].data_ptr(), P(pre + "gin_conv.eps"),
+                                                self.a[l].data_ptr(), N, H, st), "aggregate")
+            self._gemm(NT, self.a[l].data_ptr(), P(pre + "gin_conv.nn.0.weight"), P(pre + "gin_conv.nn.0.bias"), self.z1[l].data_ptr(),
+                       N, 2 * H, H, H, H, 2 * H)
+            bn1 = layer.gin_conv.nn[1]
+            cfg = self._bn_cfg(True, False, 0)
+            self._chk(lib.gmp_bn_fwd(self.z1[l].data_ptr(), None, p.d32["seg_ptr"], None, p.S, p.max_seg, N, 2 * H,
+                                     P(pre + "gin_conv.nn.1.weight"), P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(),
+                                     bn1.running_var.data_ptr(), self.stat["m1"][l].data_ptr(), self.stat["s1"][l].data_ptr(),
+                                     self.r1[l].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1")
+            self._gemm(NT, self.r1[l].data_ptr(), P(pre + "gin_conv.nn.3.weight"), P(pre + "gin_conv.nn.3.bias"), self.z2[l].data_ptr(),
+                       N, H, 2 * H, 2 * H, 2 * H, H)
+            bn2 = layer.batch_norm
+            cfg = self._bn_cfg(True, True, 10 + l)
+            self._chk(lib.gmp_bn_fwd(self.z2[l].data_ptr(), self.h[l].data_ptr(), p.d32["seg_ptr"], None, p.S, p.max_seg, N, H,
+                                     P(pre + "batch_norm.weight"), P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(),
+                                     bn2.running_var.data_ptr(), self.stat["m2"][l].data_ptr(), self.stat["s2"][l].data_ptr(),
+                                     self.h[l + 1].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2")
+
+    # ---- head helpers ------------------------------------------------------------------------------
+    def _drop(self, src: Tensor, dst: Tensor, numel: int, site: int) -> Tensor:
+        """dropout(src) -> dst (returns the tensor holding the result; p == 0 aliases src)."""
+        if not self.model.training or self.dropout_p <= 0:
+            return src
+        self._chk(self.lib.gmp_dropout_fwd(src.data_ptr(), dst.data_ptr(), numel, self.dropout_p,
+                                           (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site, self._st()), "dropout")
+        return dst
+
+    def _relu_drop_bwd(self, g: Tensor, act: Tensor, out: Tensor, numel: int, site: int) -> None:
+        p = self.dropout_p if self.model.training else 0.0
+        self._chk(self.lib.gmp_relu_dropout_bwd(g.data_ptr(), act.data_ptr(), out.data_ptr(), numel, p,
+                                                (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site, self._st()), "relu_dropout_bwd")
+
+    def _mlp2_grouped(self, ti: int, task: str, x: Tensor, rows: List[int], k_in: int, k_hid: int, k_out: int, bufs, site: int):
+        """Per-domain two-layer MLPHead (Linear-ReLU-Dropout-Linear) over row groups; returns output tensor."""
+        y1, d1, y2 = bufs
+        D = self.domains
+        w0 = [self.off[f"heads.{task}.{d}.mlp.0.weight"] for d in D]
+        b0 = [self.off[f"heads.{task}.{d}.mlp.0.bias"] for d in D]
+        w3 = [self.off[f"heads.{task}.{d}.mlp.3.weight"] for d in D]
+        b3 = [self.off[f"heads.{task}.{d}.mlp.3.bias"] for d in D]
+        fp = self.flat.data_ptr()
+        self._gemm_g(NT, x.data_ptr(), fp, fp, y1.data_ptr(), rows, w0, b0, None, None, None, 0, k_hid, k_in, k_in, k_in, k_hid, relu=True)
+        d1 = self._drop(y1, d1, rows[-1] * k_hid, site)
+        self._gemm_g(NT, d1.data_ptr(), fp, fp, y2.data_ptr(), rows, w3, b3, None, None, None, 0, k_out, k_hid, k_hid, k_hid, k_out)
+        return d1
+
+    def _mlp2_grouped_bwd(self, ti: int, task: str, x: Tensor, rows: List[int], k_in: int, k_hid: int, k_out: int, y1: Tensor, d1: Tensor,
+                          g_out: Tensor, g_hid: Tensor, g_in: Tensor, site: int) -> None:
+        """Backward of _mlp2_grouped: per-domain weight/bias gradients go straight into task_grads[ti]."""
+        D, tg, fp = self.domains, self.task_grads.data_ptr(), self.flat.data_ptr()
+        TG = self._TG
+        w0 = [self.off[f"heads.{task}.{d}.mlp.0.weight"] for d in D]
+        w3 = [self.off[f"heads.{task}.{d}.mlp.3.weight"] for d in D]
+        # dW3 = g_out^T d1, db3 = colsum(g_out)
+        self._gemm_g(TN, g_out.data_ptr(), d1.data_ptr(), None, tg, rows, None, None, [TG(ti, f"heads.{task}.{d}.mlp.3.weight") for d in D],
+                     tg, [TG(ti, f"heads.{task}.{d}.mlp.3.bias") for d in D], k_out, k_hid, 0, k_out, k_hid, k_hid)
+        # g_d1 = g_out W3
+        self._gemm_g(NN, g_out.data_ptr(), fp, None, g_hid.data_ptr(), rows, w3, None, None, None, None, 0, k_hid, k_out, k_out, k_hid, k_hid)
+        self._relu_drop_bwd(g_hid, y1, g_hid, rows[-1] * k_hid, site)
+        self._gemm_g(TN, g_hid.data_ptr(), x.data_ptr(), None, tg, rows, None, None, [TG(ti, f"heads.{task}.{d}.mlp.0.weight") for d in D],
+                     tg, [TG(ti, f"heads.{task}.{d}.mlp.0.bias") for d in D], k_hid, k_in, 0, k_hid, k_in, k_in)
+        self._gemm_g(NN, g_hid.data_ptr(), fp, None, g_in.data_ptr(), rows, w0, None, None, None, None, 0, k_in, k_hid, k_hid, k_in, k_in)
+
+    # ---- heads + backward --------------------------------------------------------------------------
+    def _heads_and_backward(self, p: StepPlan, inp: StepInputs) -> None:
+        lib, st, N, D, P, TG = self.lib, self._st(), p.N, self.domains, self._P, self._TG
+        hd, tg = self.hd, self.task_grads.data_ptr()
+        hL = self.h[GNN_NUM_LAYERS]
+        gH = self.gA
+        gH[:N].zero_()
+        sc = self.scal.data_ptr()
+        T_ = float(self.temperature)
+        for ti, t in enumerate(self.tasks):
+            gs = sc + 4 * ti                                        # device scalar 1/size_t: d total_t / d loss_sum
+            ls = self.loss_sums.data_ptr() + 4 * ti
+            if t == "node_feat_mask":
+                rows, M = p.nfm_rows, p.nfm_rows[-1]
+                if M == 0:
+                    continue
+                self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nfm_idx"], None, hd["nfm_in"].data_ptr(), M, N, H, st), "nfm gather")
+                d1 = self._mlp2_grouped(ti, t, hd["nfm_in"], rows, H, H, H, (hd["nfm_y1"], hd["nfm_d1"], hd["nfm_y2"]), 100 + ti)
+                self._chk(lib.gmp_mse_sum_fwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), M * H, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "mse")
+                self._chk(lib.gmp_mse_sum_bwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), gs, hd["nfm_g"].data_ptr(), M * H, st), "mse bwd")
+                self._mlp2_grouped_bwd(ti, t, hd["nfm_in"], rows, H, H, H, hd["nfm_y1"], d1, hd["nfm_g"], hd["nfm_g1"], hd["nfm_y2"], 100 + ti)
+                self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nfm_idx"], hd["nfm_y2"].data_ptr(), M, N, H, 0, st), "nfm scatter")
+            elif t == "link_pred":
+                K = p.lp_K
+                w0, b0 = P("heads.link_pred.predictor.mlp.0.weight"), P("heads.link_pred.predictor.mlp.0.bias")
+                w3, b3 = P("heads.link_pred.predictor.mlp.3.weight"), P("heads.link_pred.predictor.mlp.3.bias")
+                self._chk(lib.gmp_lp_edge_features_fwd(hL.data_ptr(), p.d64["lp_edges"], hd["lp_feat"].data_ptr(), N, K, H, st), "lp feat")
+                self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
+                d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
+                self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
+                self._chk(lib.gmp_sigmoid_fwd(self.lp_y2.data_ptr(), self.lp_p.data_ptr(), K, st), "sigmoid")
+                self._chk(lib.gmp_bce_sum_fwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), K, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "bce")
+                self._chk(lib.gmp_bce_sum_bwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), gs, self.lp_gp.data_ptr(), K, st), "bce bwd")
+                self._chk(lib.gmp_sigmoid_bwd(self.lp_gp.data_ptr(), self.lp_p.data_ptr(), self.lp_gy2.data_ptr(), K, st), "sigmoid bwd")
+                one = [0, K]
+                self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],
+                             tg, [TG(ti, "heads.link_pred.predictor.mlp.3.bias")], 1, H, 0, 1, H, H)
+                self._gemm(NN, self.lp_gy2.data_ptr(), w3, None, hd["lp_gy1"].data_ptr(), K, H, 1, 1, H, H)
+                self._relu_drop_bwd(hd["lp_gy1"], hd["lp_y1"], hd["lp_gy1"], K * H, 100 + ti)
+                wsb = lib.gmp_gemm_f32_workspace_bytes(TN, H, 3 * H, K)
+                if wsb > self.hd["lp_gfeat"].numel() * 4:
+                    wsb = 0
+                self._chk(lib.gmp_gemm_f32(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.weight"),
+                                           H, 3 * H, K, H, 3 * H, 3 * H, 1.0, 0, 0, hd["lp_gfeat"].data_ptr() if wsb else None, wsb, st), "lp dW0")
+                self._chk(lib.gmp_colsum(hd["lp_gy1"].data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.bias"), K, H, H, 0,
+                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "lp db0")
+                self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
+                self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
+                                                       hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")
+                c = self.lp_csr
+                self._chk(lib.gmp_csr_build(p.d64["lp_edges"], N, K, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(),
+                                            c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(), self.csr_ws.numel(), st), "lp csr")
+                self._chk(lib.gmp_segment_sum(hd["lp_ghs"].data_ptr(), c[3].data_ptr(), c[5].data_ptr(), gH.data_ptr(), N, H, 0, 1, st), "lp g by src")
+                self._chk(lib.gmp_segment_sum(hd["lp_ghd"].data_ptr(), c[0].data_ptr(), c[2].data_ptr(), gH.data_ptr(), N, H, 0, 1, st), "lp g by dst")
+            elif t == "node_contrast":
+                rows, M = p.nc_rows, p.nc_rows[-1]
+                if M == 0:
+                    continue
+                self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nc_idx"], None, hd["nc_in"].data_ptr(), M, N, H, st), "nc gather")
+                d1 = self._mlp2_grouped(ti, t, hd["nc_in"], rows, H, H, 128, (hd["nc_y1"], hd["nc_d1"], hd["nc_z"]), 100 + ti)
+                self._nt_xent_domains(p.nc_n, rows, hd["nc_z"], hd["nc_gz"], gs, ls, T_, 0)
+                self._mlp2_grouped_bwd(ti, t, hd["nc_in"], rows, H, H, 128, hd["nc_y1"], d1, hd["nc_gz"], hd["nc_g1"], hd["nc_gin"], 100 + ti)
+                self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nc_idx"], hd["nc_gin"].data_ptr(), M, N, H, 0, st), "nc scatter")
+            elif t == "graph_contrast":
+                rows, B = p.gc_rows, p.gc_B
+                if B == 0:
+                    continue
+                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gc_ptr"], None, hd["gc_mean"].data_ptr(), B, H, 1, 0, st), "gc mean")
+                self._chk(lib.gmp_segment_max_fwd(hL.data_ptr(), p.d32["gc_ptr"], hd["gc_max"].data_ptr(), B, H, st), "gc max")
+                torch.cat([hd["gc_mean"][:B], hd["gc_max"][:B]], dim=1, out=hd["gc_in"][:B])
+                d1 = self._mlp2_grouped(ti, t, hd["gc_in"], rows, 2 * H, H, 128, (hd["gc_y1"], hd["gc_d1"], hd["gc_z"]), 100 + ti)
+                self._nt_xent_domains(p.gc_n, rows, hd["gc_z"], hd["gc_gz"], gs, ls, T_, self.D)
+                self._mlp2_grouped_bwd(ti, t, hd["gc_in"], rows, 2 * H, H, 128, hd["gc_y1"], d1, hd["gc_gz"], hd["gc_g1"], hd["gc_gin"], 100 + ti)
+                hd["gc_gmean"][:B].copy_(hd["gc_gin"][:B, :H])
+                hd["gc_gmax"][:B].copy_(hd["gc_gin"][:B, H:])
+                g_rows = gH.data_ptr() + 4 * H * p.gc_r0
+                self._chk(lib.gmp_row_gather(hd["gc_gmean"].data_ptr(), p.d64["gc_gid"], p.d32["gc_ptr"], g_rows, p.gc_M, B, H, st), "gc mean bwd")
+                self._chk(lib.gmp_segment_max_bwd(hd["gc_gmax"].data_ptr(), hL.data_ptr(), hd["gc_max"].data_ptr(), p.d32["gc_ptr"], gH.data_ptr(),
+                                                  B, H, 1, st), "gc max bwd")
+            elif t == "graph_prop":
+                rows, B = p.gp_rows, p.gp_B
+                G = GRAPH_PROPERTY_DIM
+                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gp_ptr"], None, hd["gp_in"].data_ptr(), B, H, 1, 0, st), "gp mean")
+                d1 = self._mlp2_grouped(ti, t, hd["gp_in"], rows, H, 2 * H, G, (hd["gp_y1"], hd["gp_d1"], self.gp_y2), 100 + ti)
+                self._chk(lib.gmp_mse_sum_fwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), B * G, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "gp mse")
+                self._chk(lib.gmp_mse_sum_bwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), gs, self.gp_g2.data_ptr(), B * G, st), "gp mse bwd")
+                self._mlp2_grouped_bwd(ti, t, hd["gp_in"], rows, H, 2 * H, G, hd["gp_y1"], d1, self.gp_g2, hd["gp_g1"], hd["gp_gin"], 100 + ti)
+                g_rows = gH.data_ptr() + 4 * H * p.gp_r0
+                self._chk(lib.gmp_row_gather(hd["gp_gin"].data_ptr(), p.d64["gp_gid"], p.d32["gp_ptr"], g_rows, p.gp_M, B, H, st), "gp mean bwd")
+        self._backbone_backward(p, inp)
+
+    def _nt_xent_domains(self, ns: List[int], rows: List[int], z: Tensor, gz: Tensor, gs: int, ls: int, temperature: float, slot0: int) -> None:
+        """One NT-Xent problem per domain on rows [rows[d], rows[d+1]) = [z1 ; z2]; loss sums land in scal[16+slot],
+        their total in the task's loss slot."""
+        lib, st = self.lib, self._st()
+        sc = self.scal.data_ptr()
+        for di, n in enumerate(ns):
+            if n == 0:
+                continue
+            z1 = z.data_ptr() + 4 * 128 * rows[di]
+            z2 = z1 + 4 * 128 * n
+            ws = self.ntx_ws[slot0 + di]
+            need = lib.gmp_nt_xent_workspace_bytes(n, 128)
+            if need > ws.numel():
+                self.ntx_ws[slot0 + di] = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._chk(lib.gmp_nt_xent_fwd(z1, z2, n, 128, temperature, sc + 4 * (16 + slot0 + di), ws.data_ptr(), ws.numel(), st), "nt_xent")
+            g1 = gz.data_ptr() + 4 * 128 * rows[di]
+            self._chk(lib.gmp_nt_xent_bwd(z1, z2, n, 128, temperature, gs, g1, g1 + 4 * 128 * n, ws.data_ptr(), ws.numel(), st), "nt_xent bwd")
+        self._chk(lib.gmp_group_sum_1d(sc + 4 * (16 + slot0), 1, _i32([0, len(ns)]), _i64([0]), ls, st), "nt_xent total")
+
+    def _backbone_backward(self, p: StepPlan, inp: StepInputs) -> None:
+        lib, st, N, D, P, TG, T = self.lib, self._st(), p.N, self.domains, self._P, self._TG, self.T
+        tg = self.task_grads.data_ptr()
+        c = self.csr
+        gcur, gu, ga = self.gA, self.gB, self.h[GNN_NUM_LAYERS]       # h[L] is free once the heads are done: reuse as scratch
+        task_seg = [0]
+        for ti in range(T):                                            # segments are task-major
+            task_seg.append(sum(1 for s in p.seg_task if s <= ti))
+        trow = p.task_row
+        for l in reversed(range(GNN_NUM_LAYERS)):
+            pre = f"gnn_backbone.layers.{l}."
+            layer = self.model.gnn_backbone.layers[l]
+            bn2 = layer.batch_norm
+            cfg = self._bn_cfg(True, True, 10 + l)
+            self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z2[l].data_ptr(), self.h[l].data_ptr(), p.d32["seg_ptr"], None, p.S, p.max_seg, N, H,
+                                     P(pre + "batch_norm.weight"), P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(),
+                                     self.stat["m2"][l].data_ptr(), self.stat["s2"][l].data_ptr(), gu.data_ptr(), tg, tg, _i32(task_seg),
+                                     _i64([TG(t, pre + "batch_norm.weight") for t in range(T)]), _i64([TG(t, pre + "batch_norm.bias") for t in range(T)]),
+                                     T, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2 bwd")
+            self._gemm_g(TN, gu.data_ptr(), self.r1[l].data_ptr(), None, tg, trow, None, None, [TG(t, pre + "gin_conv.nn.3.weight") for t in range(T)],
+                         tg, [TG(t, pre + "gin_conv.nn.3.bias") for t in range(T)], H, 2 * H, 0, H, 2 * H, 2 * H)
+            self._gemm(NN, gu.data_ptr(), P(pre + "gin_conv.nn.3.weight"), None, self.gW.data_ptr(), N, 2 * H, H, H, 2 * H, 2 * H)
+            bn1 = layer.gin_conv.nn[1]
+            cfg = self._bn_cfg(True, False, 0)
+            self._chk(lib.gmp_bn_bwd(self.gW.data_ptr(), self.z1[l].data_ptr(), None, p.d32["seg_ptr"], None, p.S, p.max_seg, N, 2 * H,
+                                     P(pre + "gin_conv.nn.1.weight"), P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(),
+                                     self.stat["m1"][l].data_ptr(), self.stat["s1"][l].data_ptr(), self.gW2.data_ptr(), tg, tg, _i32(task_seg),
+                                     _i64([TG(t, pre + "gin_conv.nn.1.weight") for t in range(T)]), _i64([TG(t, pre + "gin_conv.nn.1.bias") for t in range(T)]),
+                                     T, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1 bwd")
+            self._gemm_g(TN, self.gW2.data_ptr(), self.a[l].data_ptr(), None, tg, trow, None, None, [TG(t, pre + "gin_conv.nn.0.weight") for t in range(T)],
+                         tg, [TG(t, pre + "gin_conv.nn.0.bias") for t in range(T)], 2 * H, H, 0, 2 * H, H, H)
+            self._gemm(NN, self.gW2.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
+            self._chk(lib.gmp_gin_aggregate_bwd_ex(ga.data_ptr(), c[3].data_ptr(), c[4].data_ptr(), P(pre + "gin_conv.eps"), self.h[l].data_ptr(),
+                                                   gu.data_ptr(), gcur.data_ptr(), self.rowdot.data_ptr(), N, H, st), "aggregate bwd")
+            self._chk(lib.gmp_group_sum_1d(self.rowdot.data_ptr(), T, _i32(trow), _i64([TG(t, pre + "gin_conv.eps") for t in range(T)]), tg, st), "eps grad")
+        # ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
+        if "node_feat_mask" in self.tasks and p.nfm_rows[-1]:
+            ti, M = self.tasks.index("node_feat_mask"), p.nfm_rows[-1]
+            self._chk(lib.gmp_row_gather(gcur.data_ptr(), p.d64["nfm_idx"], None, self.hd["nfm_in"].data_ptr(), M, N, H, st), "token rows")
+            self._chk(lib.gmp_colsum(self.hd["nfm_in"].data_ptr(), tg + 4 * TG(ti, "mask_token"), M, H, H, 0, self.loss_ws.data_ptr(),
+                                     self.loss_ws.numel(), st), "token grad")
+        seg_of: Dict[Tuple[int, int], List[int]] = {}
+        for si, (tt, dd) in enumerate(zip(p.seg_task, p.seg_dom)):
+            seg_of.setdefault((tt, dd), []).append(si)
+        groups = []                                   # (task index, domain, first segment, one-past-last segment)
+        for ti, t in enumerate(self.tasks):
+            if t == "node_feat_mask":
+                continue                              # NFM runs the encoder under no_grad (pretrain_model.py:68-69)
+            for di, d in enumerate(D):
+                segs = seg_of.get((ti, di), [])
+                if not segs:
+                    # this (task, domain) pair contributed nothing: its slots must read as zero, not as last step's values
+                    for key in ("linear.weight", "linear.bias", "batch_norm.weight", "batch_norm.bias"):
+                        n = f"input_encoders.{d}.{key}"
+                        self.task_grads[ti, self.off[n]:self.off[n] + self.numel[n]].zero_()
+                    continue
+                groups.append((ti, d, segs[0], segs[-1] + 1))
+        if not groups:
+            return
+        ptr = [groups[0][2]]
+        for (_, _, lo, hi) in groups:
+            if lo != ptr[-1]:
+                raise L.GnnmpError("engine: encoder gradient groups are not contiguous (segments must be task-major)")
+            ptr.append(hi)
+        e0 = f"input_encoders.{D[0]}."
+        cfg = self._bn_cfg(True, True, 1)
+        self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z0.data_ptr(), None, p.d32["seg_ptr"], p.d32["seg_dom"], p.S, p.max_seg, N, H,
+                                 P(e0 + "batch_norm.weight"), P(e0 + "batch_norm.bias"), self.enc_rm.data_ptr(), self.enc_rv.data_ptr(),
+                                 self.enc_mean.data_ptr(), self.enc_rstd.data_ptr(), gu.data_ptr(), tg, tg, _i32(ptr),
+                                 _i64([TG(ti, f"input_encoders.{d}.batch_norm.weight") for (ti, d, _, _) in groups]),
+                                 _i64([TG(ti, f"input_encoders.{d}.batch_norm.bias") for (ti, d, _, _) in groups]),
+                                 len(groups), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn bwd encoders")
+        d_in = [DOMAIN_DIMENSIONS[d] for d in D]
+        self._chk(lib.gmp_encoder_bwd(inp.x_all.data_ptr(), p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
+                                      gu.data_ptr(), len(D), _i32(d_in), self.dpad, len(groups), _i32(ptr),
+                                      _i64([TG(ti, f"input_encoders.{d}.linear.weight") for (ti, d, _, _) in groups]),
+                                      _i64([TG(ti, f"input_encoders.{d}.linear.bias") for (ti, d, _, _) in groups]), tg, st), "encoder bwd")
+
+    # ---- optimizer ---------------------------------------------------------------------------------
+    def _optimizer(self, p: StepPlan, order: Optional[List[str]], apply_update: bool) -> None:
+        if self.grad_sync is not None:
+            self._sync_task_grads()
+        names = list(self.tasks)
+        if order is None:
+            order = list(names)
+            if len(order) > 1:
+                (self.shuffle_rng or random).shuffle(order)       # reference: unseeded random.shuffle (gradient_surgery.py:43)
+        idx = [names.index(t) for t in order]
+        self.last_order = order
+        self._chk(self.lib.gmp_mt_pcgrad_clip_adamw(
+            self.task_grads.data_ptr(), self.P, self.T, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(),
+            _i32(idx), len(idx), self.T - 1, -1, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, self.max_grad_norm,
+            self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(), self.mt_ws.data_ptr(),
+            self.mt_ws.numel(), int(apply_update), self._st()), "mt_pcgrad_clip_adamw")
+
+    def _sync_task_grads(self) -> None:
+        """Data parallel: average the per-task gradients over ranks BEFORE PCGrad -- shared tensors once per task,
+        every head once (only its own task's row is meaningful) -- in one flat all-reduce."""
+        parts = [self.task_grads[t, :self.P_shared] for t in range(self.T)]
+        for k, n in enumerate(self.names):
+            if n.startswith("heads."):
+                t = int(np.argmax(self.has_static[k]))
+                parts.append(self.task_grads[t, self.off[n]:self.off[n] + self.numel[n]])
+        self.grad_sync.average_(parts)
+
+    # ---- reporting (the only host syncs, and only on request) ---------------------------------------
+    def losses(self) -> Dict[str, float]:
+        sums = self.loss_sums[:self.T].tolist()
+        return {t: sums[i] / max(self.last_plan.sizes[t], 1) for i, t in enumerate(self.tasks)}
+
+    def task_gradient(self, task: str, name: str) -> Tensor:
+        t = self.tasks.index(task)
+        o = self.off[name]
+        return self.task_grads[t, o:o + self.numel[name]].view_as(dict(self.model.named_parameters())[name])
+
+    def final_gradient(self, name: str) -> Tensor:
+        o = self.off[name]
+        return self.final_grad[o:o + self.numel[name]].view_as(dict(self.model.named_parameters())[name])

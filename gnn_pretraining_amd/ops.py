@@ -150,7 +150,7 @@ def segment_max_bwd(g_out: Tensor, x: Tensor, out: Tensor, ptr: Tensor) -> Tenso
     if g_out.shape != out.shape or out.size(0) != ptr.numel() - 1 or out.size(1) != F:
         raise L.GnnmpError("segment_max_bwd: shape mismatch")
     g_x = torch.empty_like(x)
-    L.check(L.lib().gmp_segment_max_bwd(_ptr(g_out), _ptr(x), _ptr(out), _ptr(ptr), _ptr(g_x), ptr.numel() - 1, F,
+    L.check(L.lib().gmp_segment_max_bwd(_ptr(g_out), _ptr(x), _ptr(out), _ptr(ptr), _ptr(g_x), ptr.numel() - 1, F, 0,
                                         _stream(x)), "gmp_segment_max_bwd")
     return g_x
 
