@@ -26,9 +26,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from gnn_pretraining_amd import dist as D, ops, synthetic as S  # noqa: E402
+from gnn_pretraining_amd.engine import StepEngine, StepInputs  # noqa: E402
 from gnn_pretraining_amd.graph import Batch  # noqa: E402
 from gnn_pretraining_amd.models import PretrainableGNN  # noqa: E402
 from gnn_pretraining_amd.pretrain import pretrain as PT  # noqa: E402
+from gnn_pretraining_amd.pretrain.control import TemperatureScheduler  # noqa: E402
 
 SCHEME = "s4"
 GRAPHS_PER_STEP = 32
@@ -55,19 +57,19 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("GMP_BENCH_MAX_CORES", "16"))))
 
 
-def make_pool(seed: int, device):
+def make_pool(seed: int, device, dpad: int):
     gen = torch.Generator().manual_seed(seed)
     domains = PT.PRETRAIN_DOMAINS[SCHEME]
-    pool = []
-    for _ in range(POOL):
-        host = S.pretrain_step_batches(gen, domains, enzymes_shaped=True)
-        pool.append({d: b.to(device) for d, b in host.items()})
-    return pool
+    return [StepInputs(S.pretrain_step_batches(gen, domains, enzymes_shaped=True), device, dpad) for _ in range(POOL)]
 
 
-def run_steps(state, pool, gen, n, start=0):
+def run_steps(engine, temperature, pool, gen, n, start=0):
+    """The body of run_training (reference pretrain.py:113-155): draw artefacts, 5 task losses, per-task
+    gradients, PCGrad, clip, AdamW, scheduler step -- one engine.step per optimisation step."""
     for i in range(n):
-        PT.train_step(state, pool[(start + i) % len(pool)], gen)
+        engine.temperature = temperature()
+        engine.step(pool[(start + i) % len(pool)], gen)
+        temperature.step()
 
 
 def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iters: int = 20):
@@ -157,19 +159,20 @@ def main() -> None:
     model = PretrainableGNN(device, PT.PRETRAIN_DOMAINS[SCHEME], PT.ACTIVE_TASKS[SCHEME])
     model.train()
     sync = D.FlatGradSync() if world > 1 else None
-    state = PT.StepState(model, PT.PretrainConfig(SCHEME, seed), steps_per_epoch=462, grad_sync=sync,
-                         shuffle_rng=random.Random(seed))
-    pool = make_pool(seed + 1000 * rank, device)   # every rank draws its own batches (weak scaling)
+    engine = StepEngine(model, PT.ACTIVE_TASKS[SCHEME], PT.PRETRAIN_DOMAINS[SCHEME], device, seed=seed + rank,
+                        shuffle_rng=random.Random(seed), grad_sync=sync)     # same PCGrad task order on every rank
+    temperature = TemperatureScheduler(total_steps=462 * PT.EPOCHS)
+    pool = make_pool(seed + 1000 * rank, device, engine.dpad)   # every rank draws its own batches (weak scaling)
     gen = torch.Generator().manual_seed(seed + rank)
 
     log(f"rank {rank}/{world}: model + {POOL} step inputs resident, warming up {a.warmup} steps")
-    run_steps(state, pool, gen, a.warmup)
+    run_steps(engine, temperature, pool, gen, a.warmup)
     log("timing")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    run_steps(state, pool, gen, a.steps, start=a.warmup)
+    run_steps(engine, temperature, pool, gen, a.steps, start=a.warmup)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
@@ -179,7 +182,7 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    log(f"{a.steps} steps in {elapsed:.3f} s")
+    log(f"{a.steps} steps in {elapsed:.3f} s; last-step losses {engine.losses()}")
     roof = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)

@@ -17,6 +17,7 @@ constexpr int DPAD_MAX = 64;
 
 struct EncArgs {
     const float* x_all;         // [R, dpad]
+    int num_x_rows, num_rows, num_segs;   // bounds: a bad index reads as zero instead of faulting
     const int* src_row;         // [N] row of x_all feeding stacked row r
     const int* seg_ptr;         // [S+1]
     const int* seg_dom;         // [S]
@@ -33,7 +34,8 @@ template <int DP>
 __global__ __launch_bounds__(H) void encoder_fwd_kernel(EncArgs a) {
     __shared__ float xs[TR][DP + 1];
     const int seg = a.tiles[2 * blockIdx.x], r0 = a.tiles[2 * blockIdx.x + 1];
-    const int r1 = min(r0 + TR, a.seg_ptr[seg + 1]);
+    if (seg < 0 || seg >= a.num_segs || r0 < 0 || r0 >= a.num_rows) return;
+    const int r1 = min(min(r0 + TR, a.seg_ptr[seg + 1]), a.num_rows);
     const int dom = a.seg_dom[seg], din = a.d_in[dom];
     const int c = threadIdx.x;
     for (int i = c; i < TR * DP; i += H) {
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(H) void encoder_fwd_kernel(EncArgs a) {
         float v = 0.f;
         if (r0 + rr < r1 && k < din) {
             const unsigned long long mask = a.row_colmask ? a.row_colmask[r0 + rr] : 0ull;
-            if (!((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+            const int sr = a.src_row[r0 + rr];
+            if (!((mask >> k) & 1ull) && sr >= 0 && sr < a.num_x_rows) v = a.x_all[(int64_t)sr * a.dpad + k];
         }
         xs[rr][k] = v;
     }
@@ -65,6 +68,7 @@ struct EncBwdArgs {
     const int* seg_ptr;
     const int* seg_dom;
     const unsigned long long* row_colmask;
+    int num_x_rows, num_rows, num_segs;
     const float* gz;            // [N, 256]
     int dpad;
     int d_in[MAXD];
@@ -83,18 +87,20 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) acc[k] = 0.f;
     int din = 0;
-    for (int seg = a.gseg[g]; seg < a.gseg[g + 1]; ++seg) {
+    for (int seg = max(a.gseg[g], 0); seg < min(a.gseg[g + 1], a.num_segs); ++seg) {
         const int dom = a.seg_dom[seg];
         din = a.d_in[dom];
-        for (int r0 = a.seg_ptr[seg]; r0 < a.seg_ptr[seg + 1]; r0 += TR) {
-            const int r1 = min(r0 + TR, a.seg_ptr[seg + 1]);
+        const int s1 = min(a.seg_ptr[seg + 1], a.num_rows);
+        for (int r0 = max(a.seg_ptr[seg], 0); r0 < s1; r0 += TR) {
+            const int r1 = min(r0 + TR, s1);
             __syncthreads();
             for (int i = c; i < TR * DP; i += H) {
                 const int rr = i / DP, k = i % DP;
                 float v = 0.f;
                 if (r0 + rr < r1 && k < din) {
                     const unsigned long long mask = a.row_colmask ? a.row_colmask[r0 + rr] : 0ull;
-                    if (!((mask >> k) & 1ull)) v = a.x_all[(int64_t)a.src_row[r0 + rr] * a.dpad + k];
+                    const int sr = a.src_row[r0 + rr];
+                    if (!((mask >> k) & 1ull) && sr >= 0 && sr < a.num_x_rows) v = a.x_all[(int64_t)sr * a.dpad + k];
                 }
                 xs[rr][k] = v;
             }
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
 
 }  // namespace
 
-extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+extern "C" int gmp_encoder_fwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                                const uint64_t* row_colmask, const int32_t* tiles, int num_tiles, const float* params,
                                int num_domains, const int64_t* w_off_host, const int64_t* b_off_host,
                                const int32_t* d_in_host, int dpad, float* z, gmp_stream_t stream) {
@@ -128,6 +134,7 @@ extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const
     if (!x_all || !src_row || !seg_ptr || !seg_dom || !tiles || !params || !w_off_host || !b_off_host || !d_in_host || !z)
         return gmp::fail(GMP_ERR_ARG, "encoder_fwd: null pointer");
     EncArgs a{};
+    a.num_x_rows = (int)num_x_rows; a.num_rows = (int)num_rows; a.num_segs = num_segments;
     a.x_all = x_all; a.src_row = src_row; a.seg_ptr = seg_ptr; a.seg_dom = seg_dom;
     a.row_colmask = (const unsigned long long*)row_colmask; a.tiles = tiles; a.params = params; a.dpad = dpad; a.z = z;
     for (int d = 0; d < num_domains; ++d) {
@@ -142,7 +149,7 @@ extern "C" int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const
     return gmp::check_launch("encoder_fwd_kernel");
 }
 
-extern "C" int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+extern "C" int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                                const uint64_t* row_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
                                int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
                                const int64_t* off_b_host, float* grad_out, gmp_stream_t stream) {
@@ -152,6 +159,7 @@ extern "C" int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const
     if (!x_all || !src_row || !seg_ptr || !seg_dom || !g_z || !d_in_host || !group_seg_host || !off_w_host || !off_b_host || !grad_out)
         return gmp::fail(GMP_ERR_ARG, "encoder_bwd: null pointer");
     EncBwdArgs a{};
+    a.num_x_rows = (int)num_x_rows; a.num_rows = (int)num_rows; a.num_segs = num_segments;
     a.x_all = x_all; a.src_row = src_row; a.seg_ptr = seg_ptr; a.seg_dom = seg_dom;
     a.row_colmask = (const unsigned long long*)row_colmask; a.gz = g_z; a.dpad = dpad; a.groups = groups; a.out = grad_out;
     for (int d = 0; d < num_domains; ++d) a.d_in[d] = d_in_host[d];

@@ -219,11 +219,15 @@ class StepEngine:
         self.scal = torch.zeros(64, device=dev)              # device scalars: 1/size per task, NT-Xent losses ...
         # packed per-step index uploads (pinned staging)
         self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536, 4 * self.max_edges + 8 * R
-        self.pin32 = torch.empty(self.i32_cap, dtype=torch.int32).pin_memory()
-        self.pin64 = torch.empty(self.i64_cap, dtype=torch.int64).pin_memory()
+        # The host runs several steps ahead of the GPU (nothing in a step syncs), so the pinned staging buffers
+        # form a ring: a slot is refilled only after the copy that last read it has completed (event per slot).
+        self.STAGES = 4
+        self.stage = [{"pin32": torch.empty(self.i32_cap, dtype=torch.int32).pin_memory(),
+                       "pin64": torch.empty(self.i64_cap, dtype=torch.int64).pin_memory(),
+                       "pinf": torch.empty(64 + self.KMAX, dtype=torch.float32).pin_memory(),
+                       "event": None} for _ in range(self.STAGES)]
         self.dev32 = torch.empty(self.i32_cap, dtype=torch.int32, device=dev)
         self.dev64 = torch.empty(self.i64_cap, dtype=torch.int64, device=dev)
-        self.pinf = torch.empty(64, dtype=torch.float32).pin_memory()
 
     # ------------------------------------------------------------------ host: plan one step
     def draw(self, inp: StepInputs, gen: torch.Generator) -> Dict[str, object]:
@@ -381,6 +385,10 @@ class StepEngine:
     def _upload(self, p: StepPlan, inp: StepInputs, art) -> None:
         lay32, lay64 = {}, {}
         cur = {"o32": 0, "o64": 0}
+        slot = self.stage[self.step_count % self.STAGES]
+        if slot["event"] is not None:
+            slot["event"].synchronize()                  # the copy that read this slot STAGES steps ago is done
+        self.pin32, self.pin64, self.pinf = slot["pin32"], slot["pin64"], slot["pinf"]
 
         def put32(name: str, arr) -> None:
             a = np.ascontiguousarray(np.asarray(arr, dtype=np.int32).reshape(-1))
@@ -482,12 +490,16 @@ class StepEngine:
         o32, o64 = cur["o32"], cur["o64"]
         self.dev32[:o32].copy_(self.pin32[:o32], non_blocking=True)
         self.dev64[:o64].copy_(self.pin64[:o64], non_blocking=True)
-        self.pinf.zero_()
+        self.pinf[:64].zero_()
         for ti, t in enumerate(self.tasks):
             self.pinf[ti] = 1.0 / max(sizes[t], 1)
-        self.scal.copy_(self.pinf, non_blocking=True)          # [0:8) = 1/size per task, [16:48) = per-domain NT-Xent sums (zeroed)
+        self.scal.copy_(self.pinf[:64], non_blocking=True)     # [0:8) = 1/size per task, [16:48) = per-domain NT-Xent sums (zeroed)
         if "link_pred" in self.tasks:
-            self.lp_lab[:p.lp_K].copy_(torch.from_numpy(p.lp_labels), non_blocking=True)
+            self.pinf[64:64 + p.lp_K] = torch.from_numpy(p.lp_labels)
+            self.lp_lab[:p.lp_K].copy_(self.pinf[64:64 + p.lp_K], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot["event"] = ev
         b32, b64 = self.dev32.data_ptr(), self.dev64.data_ptr()
         p.d32 = {k: b32 + 4 * o for k, o in lay32.items()}
         p.d64 = {k: b64 + 8 * o for k, o in lay64.items()}
@@ -521,7 +533,7 @@ class StepEngine:
         w_off = [self.off[f"input_encoders.{d}.linear.weight"] for d in D]
         b_off = [self.off[f"input_encoders.{d}.linear.bias"] for d in D]
         d_in = [DOMAIN_DIMENSIONS[d] for d in D]
-        self._chk(lib.gmp_encoder_fwd(inp.x_all.data_ptr(), p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
+        self._chk(lib.gmp_encoder_fwd(inp.x_all.data_ptr(), inp.x_all.size(0), N, p.S, p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
                                       p.d32["tiles"], p.num_tiles, self.flat.data_ptr(), len(D), _i64(w_off), _i64(b_off), _i32(d_in),
                                       self.dpad, self.z0.data_ptr(), st), "encoder_fwd")
         cfg = self._bn_cfg(True, True, 1)
@@ -784,7 +796,7 @@ class StepEngine:
                                  _i64([TG(ti, f"input_encoders.{d}.batch_norm.bias") for (ti, d, _, _) in groups]),
                                  len(groups), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn bwd encoders")
         d_in = [DOMAIN_DIMENSIONS[d] for d in D]
-        self._chk(lib.gmp_encoder_bwd(inp.x_all.data_ptr(), p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
+        self._chk(lib.gmp_encoder_bwd(inp.x_all.data_ptr(), inp.x_all.size(0), N, p.S, p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
                                       gu.data_ptr(), len(D), _i32(d_in), self.dpad, len(groups), _i32(ptr),
                                       _i64([TG(ti, f"input_encoders.{d}.linear.weight") for (ti, d, _, _) in groups]),
                                       _i64([TG(ti, f"input_encoders.{d}.linear.bias") for (ti, d, _, _) in groups]), tg, st), "encoder bwd")

@@ -271,14 +271,15 @@ int gmp_row_fill(float* dst, const int64_t* idx, const float* src, int64_t num_i
  * r reads x_all[src_row[r]]; segment s belongs to domain seg_dom[s] (weights at params + w_off_host[d],
  * shape [256, d_in_host[d]], bias at params + b_off_host[d]); row_colmask[r] (nullable) bit k = feature k of stacked row r zeroed
  * (attribute-mask augmentation, augmentations.py:17-29).  tiles [num_tiles][2] = (segment, first row),
- * 32 rows each.  bwd: one gradient group per (task, domain) pair covering segments
+ * 32 rows each; indices outside [0,num_x_rows) / [0,num_rows) / [0,num_segments) read as zero rows.
+ * bwd: one gradient group per (task, domain) pair covering segments
  * group_seg_host[g]..[g+1]; dW lands at grad_out + off_w_host[g] ([256, d_in]), db at + off_b_host[g].
  * ------------------------------------------------------------------------- */
-int gmp_encoder_fwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+int gmp_encoder_fwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                     const uint64_t* row_colmask, const int32_t* tiles, int num_tiles, const float* params,
                     int num_domains, const int64_t* w_off_host, const int64_t* b_off_host,
                     const int32_t* d_in_host, int dpad, float* z, gmp_stream_t stream);
-int gmp_encoder_bwd(const float* x_all, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
+int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                     const uint64_t* row_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
                     int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
                     const int64_t* off_b_host, float* grad_out, gmp_stream_t stream);

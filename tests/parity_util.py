@@ -47,7 +47,7 @@ def assert_grad_close(got, want, gmax, what=""):
     by ~1e-3.  scripts/diag_precision.py shows both implementations otherwise sit 2-7e-7 from fp64.
     scripts/diag_tasks_fp64.py shows the error is bimodal -- ~1e-6 without a flip, ~1e-3 with one -- and
     that the fp32 ORACLE shows the same flips against its own fp64 run (up to 1e-1 on a scalar eps
-    gradient).  So: max-norm within 3e-2, L2 within 1e-2, measured against max(|want|, 1e-3 * largest
+    gradient).  So: max-norm within 1e-1, L2 within 1e-2, measured against max(|want|, 1e-3 * largest
     gradient) (the floor covers analytically-zero gradients such as a bias feeding a train-mode BatchNorm).
     Flip-free gradient checks at 1e-4 .. 2e-4 are the per-operator tests in test_gpu_ops.py."""
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
@@ -58,4 +58,4 @@ def assert_grad_close(got, want, gmax, what=""):
     floor = gmax if want.numel() == 1 else 1e-3 * gmax
     e_max = d.abs().max().item() / max(want.abs().max().item(), floor, 1e-30)
     e_l2 = d.norm().item() / max(want.norm().item(), floor * want.numel() ** 0.5, 1e-30)
-    assert e_max <= 3e-2 and e_l2 <= 1e-2, f"{what}: max-norm rel {e_max:.3e}, L2 rel {e_l2:.3e}"
+    assert e_max <= 1e-1 and e_l2 <= 1e-2, f"{what}: max-norm rel {e_max:.3e}, L2 rel {e_l2:.3e}"
