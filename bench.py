@@ -103,7 +103,7 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     alg_bytes = 2 * 4 * 256 * N + 4 * (N + 1) + 4 * E
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "seg_sum_kernel<1,SELF,IDX> (gmp_gin_aggregate_fwd)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "gin_aggregate_stream_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters}
 
 

@@ -109,6 +109,69 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming form for inputs that do not fit the caches (the 65,536-graph rung: x = 2.2 GB).
+// What limits the one-wave-per-chunk kernel above at that size is not bandwidth but (a) three dependent
+// memory latencies per row (rowptr -> col -> rows) and (b) no cache reuse: 8192 waves each walking their
+// own distant chunk keep ~270 MB of "current graphs" live, so a neighbour row (wanted ~4.8 times) is usually
+// re-fetched from HBM.  Here a 1024-thread workgroup owns a contiguous span and its 16 waves take ADJACENT
+// rows of a 256-row tile, so the whole CU works inside one or two graphs (~66 KB: L1/L2 resident) and every
+// row of x leaves HBM once; rowptr and col of a tile are staged into LDS with two coalesced block-wide
+// loads, leaving ONE memory latency per row; the output is written with non-temporal stores so it does not
+// evict the x rows waiting to be re-read.
+constexpr int SB = 1024, SWAVES = SB / GMP_WAVE, TILE = 256, COLCAP = 3072;
+
+__global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
+                                                                  const int* __restrict__ col, const float* __restrict__ eps,
+                                                                  float4* __restrict__ out, int64_t nrows, int tiles_per_block) {
+    __shared__ int s_ptr[TILE + 1];
+    __shared__ int s_col[COLCAP];
+    const int per_xcd = gridDim.x / NUM_XCD;
+    const int lb = (blockIdx.x % NUM_XCD) * per_xcd + blockIdx.x / NUM_XCD;
+    const int lane = threadIdx.x % GMP_WAVE, wv = threadIdx.x / GMP_WAVE;
+    const float scale = 1.f + (eps ? eps[0] : 0.f);
+    const int64_t ntiles = (nrows + TILE - 1) / TILE;
+    const int64_t t0 = (int64_t)lb * tiles_per_block;
+    for (int64_t t = t0; t < t0 + tiles_per_block && t < ntiles; ++t) {
+        const int64_t r0 = t * TILE;
+        const int nr = (int)(nrows - r0 < TILE ? nrows - r0 : TILE);
+        __syncthreads();                                   // everyone is done with the previous tile's LDS
+        for (int i = threadIdx.x; i <= nr; i += SB) s_ptr[i] = rowptr[r0 + i];
+        __syncthreads();
+        const int base = s_ptr[0], cnt = s_ptr[nr] - base;
+        const bool staged = cnt <= COLCAP;
+        if (staged)
+            for (int i = threadIdx.x; i < cnt; i += SB) s_col[i] = col[base + i];
+        __syncthreads();
+        for (int rr = wv; rr < nr; rr += SWAVES) {
+            const int64_t r = r0 + rr;
+            const int start = s_ptr[rr], end = s_ptr[rr + 1];
+            float4 acc = x[r * 64 + lane];
+            acc = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
+            int e = start;
+            for (; e + 4 <= end; e += 4) {
+                int c0, c1, c2, c3;
+                if (staged) { c0 = s_col[e - base]; c1 = s_col[e - base + 1]; c2 = s_col[e - base + 2]; c3 = s_col[e - base + 3]; }
+                else { c0 = col[e]; c1 = col[e + 1]; c2 = col[e + 2]; c3 = col[e + 3]; }
+                const int64_t u0 = __builtin_amdgcn_readfirstlane(c0), u1 = __builtin_amdgcn_readfirstlane(c1);
+                const int64_t u2 = __builtin_amdgcn_readfirstlane(c2), u3 = __builtin_amdgcn_readfirstlane(c3);
+                const float4 a = x[u0 * 64 + lane], b = x[u1 * 64 + lane], c = x[u2 * 64 + lane], d = x[u3 * 64 + lane];
+                acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
+            }
+            for (; e < end; ++e) {
+                const int cc = staged ? s_col[e - base] : col[e];
+                const int64_t u = __builtin_amdgcn_readfirstlane(cc);
+                acc = f4add(acc, x[u * 64 + lane]);
+            }
+            float* o = reinterpret_cast<float*>(out + r * 64 + lane);
+            __builtin_nontemporal_store(acc.x, o);
+            __builtin_nontemporal_store(acc.y, o + 1);
+            __builtin_nontemporal_store(acc.z, o + 2);
+            __builtin_nontemporal_store(acc.w, o + 3);
+        }
+    }
+}
+
 // any feature width: one thread per output element (class logits, 12 graph properties ...)
 __global__ __launch_bounds__(BLOCK) void seg_sum_scalar_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
                                                                const int* __restrict__ idx, float* __restrict__ out,
@@ -187,6 +250,14 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N < 0 || (N > 0 && (!x || !rowptr || !out))) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd: null pointer");
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
+    if (feat == 256 && N >= 65536) {          // working set beyond the caches: streaming kernel
+        const int64_t ntiles = (N + TILE - 1) / TILE;
+        int blocks = 512;                       // 2 resident 1024-thread workgroups per CU
+        int tpb = (int)((ntiles + blocks - 1) / blocks);
+        hipLaunchKernelGGL(gin_aggregate_stream_kernel, dim3(blocks), dim3(SB), 0, (hipStream_t)stream, (const float4*)x, rowptr, col,
+                           eps, (float4*)out, N, tpb);
+        return gmp::check_launch("gin_aggregate_stream_kernel");
+    }
     Plan p = make_plan(N);
     return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, (hipStream_t)stream, x, rowptr, col, x, eps,
                                                       nullptr, out, nullptr, N, F4);

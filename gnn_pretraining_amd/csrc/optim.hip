@@ -3,7 +3,7 @@
 //
 // The reference walks ~62 shared tensors x 10 task pairs with three host syncs each (norm()==0,
 // dot<0) -- about 1,900 device->host round trips per s4 step.  Here the whole thing is five launches:
-//   gram     one block per tensor: every <g_i, g_j> of that tensor              (per-tensor, not whole-model,
+//   gram     32 blocks per tensor + a finish pass: every <g_i, g_j> of that tensor (per-tensor, not whole-model,
 //   solve    one thread per tensor: PCGrad's sequential projections solved in    exactly as the reference)
 //            5x5 Gram space -> per-task mixing weights, plus the reference's
 //            "which tensors get a gradient at all" rule (its _set_gradients quirk)
@@ -17,6 +17,7 @@ namespace {
 
 constexpr int MAXT = 8;        // tasks
 constexpr int CH = 8;          // chunks per tensor in the elementwise kernels
+constexpr int GCH = 32;        // chunks per tensor in the Gram pass (the 131k-element weights need many blocks)
 constexpr int TB = 256;
 
 struct MtArgs {
@@ -27,6 +28,7 @@ struct MtArgs {
     const int* len;            // [K]
     const unsigned char* has;  // [K][MAXT]
     double* gram;              // [K][MAXT][MAXT]
+    double* gram_part;         // [K][GCH][MAXT][MAXT] chunk partials
     float* weights;            // [K][MAXT]
     int* flags;                // [K]
     float* steps;              // [K]
@@ -47,45 +49,49 @@ struct MtArgs {
 };
 
 __global__ __launch_bounds__(TB) void gram_kernel(MtArgs a) {
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, j = blockIdx.y;
     int holders[MAXT], nh = 0;
     for (int t = 0; t < a.T; ++t)
         if (a.has[k * MAXT + t]) holders[nh++] = t;
     if (nh < 2) return;                         // nothing to project against
-    float acc[MAXT * (MAXT + 1) / 2];
     const int npair = nh * (nh + 1) / 2;
+    const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
+    const int lo = j * per, hi = min(lo + per, len);
+    double* out = a.gram_part + ((int64_t)k * GCH + j) * (MAXT * MAXT);
+    float acc[MAXT * (MAXT + 1) / 2];
     for (int p = 0; p < npair; ++p) acc[p] = 0.f;
     const int64_t off = a.off[k];
-    __shared__ double sh[TB];
-    double tot[MAXT * (MAXT + 1) / 2];
-    for (int p = 0; p < npair; ++p) tot[p] = 0.0;
-    // fp32 partials over short strips, widened to double before they are combined
-    for (int base = 0; base < a.len[k]; base += TB * 64) {
-        for (int p = 0; p < npair; ++p) acc[p] = 0.f;
-        for (int i = base + threadIdx.x; i < a.len[k] && i < base + TB * 64; i += TB) {
-            float g[MAXT];
-            for (int h = 0; h < nh; ++h) g[h] = a.tg[(int64_t)holders[h] * a.stride + off + i];
-            int p = 0;
-            for (int x = 0; x < nh; ++x)
-                for (int y = x; y < nh; ++y) acc[p++] += g[x] * g[y];
-        }
-        for (int p = 0; p < npair; ++p) tot[p] += (double)acc[p];
+    for (int i = lo + threadIdx.x; i < hi; i += TB) {     // <= 16 elements per thread: fp32 partials are exact enough
+        float g[MAXT];
+        for (int h = 0; h < nh; ++h) g[h] = a.tg[(int64_t)holders[h] * a.stride + off + i];
+        int p = 0;
+        for (int x = 0; x < nh; ++x)
+            for (int y = x; y < nh; ++y) acc[p++] += g[x] * g[y];
     }
+    __shared__ double sh[TB];
     int p = 0;
     for (int x = 0; x < nh; ++x)
         for (int y = x; y < nh; ++y, ++p) {
             __syncthreads();
-            sh[threadIdx.x] = tot[p];
+            sh[threadIdx.x] = (double)acc[p];
             __syncthreads();
             for (int d = TB / 2; d > 0; d >>= 1) {
                 if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
                 __syncthreads();
             }
-            if (threadIdx.x == 0) {
-                a.gram[((int64_t)k * MAXT + holders[x]) * MAXT + holders[y]] = sh[0];
-                a.gram[((int64_t)k * MAXT + holders[y]) * MAXT + holders[x]] = sh[0];
-            }
+            if (threadIdx.x == 0) out[holders[x] * MAXT + holders[y]] = sh[0];
         }
+}
+
+// sum the chunk partials in chunk order into the symmetric Gram matrix of every tensor
+__global__ __launch_bounds__(64) void gram_finish_kernel(MtArgs a) {
+    const int k = blockIdx.x, x = threadIdx.x / MAXT, y = threadIdx.x % MAXT;
+    if (x >= a.T || y >= a.T || x > y) return;
+    if (!a.has[k * MAXT + x] || !a.has[k * MAXT + y]) return;
+    double s = 0.0;
+    for (int j = 0; j < GCH; ++j) s += a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + x * MAXT + y];
+    a.gram[((int64_t)k * MAXT + x) * MAXT + y] = s;
+    a.gram[((int64_t)k * MAXT + y) * MAXT + x] = s;
 }
 
 __global__ __launch_bounds__(TB) void solve_kernel(MtArgs a) {
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
 
 extern "C" size_t gmp_mt_workspace_bytes(int num_tensors) {
     const size_t K = num_tensors > 0 ? num_tensors : 0;
-    return K * MAXT * MAXT * sizeof(double) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) + 1024;
+    return K * MAXT * MAXT * sizeof(double) * (1 + GCH) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) + 1024;
 }
 
 extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
@@ -251,6 +257,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
     a.has = has;
     char* w = (char*)ws;
     a.gram = (double*)w; w += (size_t)num_tensors * MAXT * MAXT * sizeof(double);
+    a.gram_part = (double*)w; w += (size_t)num_tensors * GCH * MAXT * MAXT * sizeof(double);
     a.weights = (float*)w; w += (size_t)num_tensors * MAXT * sizeof(float);
     a.partial = (float*)w; w += (size_t)num_tensors * CH * sizeof(float);
     a.flags = flags_out; a.steps = steps; a.metrics = metrics_out;
@@ -262,7 +269,10 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
     a.final_grad = final_grad; a.normsq = normsq_out; a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
     a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
     hipStream_t st = (hipStream_t)stream;
-    if (n_order > 1) hipLaunchKernelGGL(gram_kernel, dim3(num_tensors), dim3(TB), 0, st, a);
+    if (n_order > 1) {
+        hipLaunchKernelGGL(gram_kernel, dim3(num_tensors, GCH), dim3(TB), 0, st, a);
+        hipLaunchKernelGGL(gram_finish_kernel, dim3(num_tensors), dim3(64), 0, st, a);
+    }
     hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(TB), 0, st, a);
     hipLaunchKernelGGL(combine_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
     hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);

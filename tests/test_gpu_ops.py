@@ -86,6 +86,26 @@ def test_gin_aggregate_fwd_bwd(graphs, F):
     close(ge, er.grad, what="aggregate g_eps", scale=(g * x).abs().sum().item() / (n * F) ** 0.5)
 
 
+def test_gin_aggregate_streaming_kernel():
+    """N >= 65,536 rows takes the LDS-staged streaming kernel (the roofline rung's path); a dense random graph
+    forces its un-staged fallback (more neighbour ids per 256-row tile than the LDS stage holds)."""
+    gen = torch.Generator().manual_seed(77)
+    b = S.domain_batch(gen, 4, 2100)                        # ~69k rows of ENZYMES-shaped graphs
+    n = b.num_nodes
+    assert n >= 65536
+    x = torch.randn(n, 256, generator=gen)
+    eps = torch.tensor([0.2])
+    csr = ops.csr_build(b.edge_index.to(DEV), n)
+    out = ops.gin_aggregate_fwd(x.to(DEV), csr.rowptr, csr.col, eps.to(DEV))
+    close(out, OG.gin_aggregate(x, b.edge_index, eps), what="streaming aggregate")
+    n2 = 66000
+    ei = torch.randint(0, n2, (2, 1_400_000), generator=gen)
+    x2 = torch.randn(n2, 256, generator=gen)
+    csr = ops.csr_build(ei.to(DEV), n2)
+    out = ops.gin_aggregate_fwd(x2.to(DEV), csr.rowptr, csr.col, eps.to(DEV))
+    close(out, OG.gin_aggregate(x2, ei, eps), what="streaming aggregate, un-staged tiles")
+
+
 def test_gin_aggregate_isolated_and_empty():
     x = torch.randn(5, 256)
     ei = torch.tensor([[0, 1], [1, 0]])
