@@ -107,6 +107,27 @@ class JsonlLogger:
             self.f.flush()
 
 
+def run_training_engine(state: StepState, engine, steps: int, generator: torch.Generator, device, epoch: int,
+                        global_step: List[int], logger: JsonlLogger, log_every: int = 50) -> None:
+    """run_training on the stacked-step engine: same step semantics, one fused forward/backward per step.
+    Losses are read back only every `log_every` steps (the reference syncs ~2,000 times per step to log)."""
+    from ..engine import StepInputs
+    state.model.train()
+    for _ in range(steps):
+        global_step[0] += 1
+        inp = StepInputs(synthetic.pretrain_step_batches(generator, state.cfg.pretrain_domains), device, engine.dpad)
+        engine.temperature = state.temperature()
+        engine.step(inp, generator)
+        state.grl.step()
+        state.temperature.step()
+        if global_step[0] % log_every == 0:
+            m = {f"train/loss/{t}": v for t, v in engine.losses().items()}
+            conf, proj = engine.metrics.tolist()
+            m.update({"train/progress/epoch": epoch, "gradient_surgery/total_conflicts": conf,
+                      "gradient_surgery/total_projections": proj, "gradient_surgery/conflict_ratio": conf / max(proj, 1)})
+            logger.log(m, global_step[0])
+
+
 def run_training(state: StepState, steps: int, generator: torch.Generator, device, epoch: int, global_step: List[int],
                  logger: JsonlLogger) -> None:
     state.model.train()
@@ -159,11 +180,18 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: int = 4
     model = PretrainableGNN(device=dev, domain_names=cfg.pretrain_domains, task_names=cfg.active_tasks)
     state = StepState(model, cfg, steps_per_epoch, epochs)
     logger = JsonlLogger(log_path)
+    engine = None
+    from ..engine import SUPPORTED_TASKS, StepEngine
+    if all(t in SUPPORTED_TASKS for t in cfg.active_tasks):       # s5's domain_adv runs on the module path
+        engine = StepEngine(model, cfg.active_tasks, cfg.pretrain_domains, dev, seed=cfg.seed)
     best, stale, global_step = float("inf"), 0, [0]
     path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"
     for epoch in range(1, epochs + 1):
         t0 = time.time()
-        run_training(state, steps_per_epoch, generator, dev, epoch, global_step, logger)
+        if engine is not None:
+            run_training_engine(state, engine, steps_per_epoch, generator, dev, epoch, global_step, logger)
+        else:
+            run_training(state, steps_per_epoch, generator, dev, epoch, global_step, logger)
         val = run_evaluation(state, generator, dev)
         logger.log({"val/loss/total": val, "epoch_seconds": time.time() - t0}, global_step[0])
         if val < best:

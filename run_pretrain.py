@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Pre-training CLI with the reference's flags (run_pretrain.py:82-98): --sweep | --exp_name S --seed N.
+Each experiment runs as a child process (`python -m gnn_pretraining_amd.pretrain.pretrain`) with PYTHONPATH=cwd;
+a failing child makes this script exit 1 with the child's stderr in the message.  Extra flags after `--` are
+passed through to the child (e.g. `-- --epochs 1 --steps-per-epoch 20`)."""
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from itertools import product
+from pathlib import Path
+
+SCHEMES = ["b2", "b3", "b4", "s1", "s2", "s3", "s4", "s5"]
+SEEDS = [42, 84, 126]
+
+
+def num_gpus() -> int:
+    try:
+        import torch
+        return max(torch.cuda.device_count(), 1)
+    except Exception:
+        return 1
+
+
+def run_one(job):
+    exp_name, seed, extra, gpu = job
+    env = dict(os.environ, PYTHONPATH=str(Path.cwd()))
+    if gpu is not None:
+        env["HIP_VISIBLE_DEVICES"] = str(gpu)          # the reference does not pin devices; one child per GPU here
+    cmd = [sys.executable, "-m", "gnn_pretraining_amd.pretrain.pretrain", "--exp_name", exp_name, "--seed", str(seed)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    if r.returncode:
+        msg = f"Exit code {r.returncode}: {r.stderr}"
+        print(f"x Failed: {exp_name} (seed={seed}) - {msg}")
+        return False, exp_name, seed, msg
+    print(f"ok Completed: {exp_name} (seed={seed})")
+    return True, exp_name, seed, None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser(description="Run pretraining experiments")
+    ap.add_argument("--sweep", action="store_true", help="Run full parameter sweep")
+    ap.add_argument("--exp_name", type=str, help="Experiment name")
+    ap.add_argument("--seed", type=int, help="Random seed")
+    args, extra = ap.parse_known_args()
+    extra = [e for e in extra if e != "--"]
+    if args.sweep:
+        jobs = list(product(SCHEMES, SEEDS))
+        n = num_gpus()
+        print(f"Starting pretraining sweep: {len(jobs)} experiments on {n} GPU(s)")
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            results = list(ex.map(run_one, [(e, s, extra, i % n) for i, (e, s) in enumerate(jobs)]))
+        failed = [r for r in results if not r[0]]
+        print(f"ok {len(results) - len(failed)}  failed {len(failed)}")
+        for _, e, s, msg in failed:
+            print(f"  - {e} (seed={s}): {msg}")
+    elif args.exp_name:
+        ok, _, _, msg = run_one((args.exp_name, args.seed, extra, None))
+        if not ok:
+            print(f"Experiment failed: {msg}")
+            sys.exit(1)
+    else:
+        print("Please specify either --sweep or --exp_name + --seed")
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
