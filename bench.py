@@ -144,6 +144,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rng", choices=["reference", "vectorized"], default="vectorized",
+                    help="how the step's augmentation/mask/negative indices are drawn on the host: 'reference' = the exact "
+                         "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
+                         "distributions, all graphs of a domain at once (numpy)")
     a = ap.parse_args()
 
     world = D.init_from_env()
@@ -160,7 +164,7 @@ def main() -> None:
     model.train()
     sync = D.FlatGradSync() if world > 1 else None
     engine = StepEngine(model, PT.ACTIVE_TASKS[SCHEME], PT.PRETRAIN_DOMAINS[SCHEME], device, seed=seed + rank,
-                        shuffle_rng=random.Random(seed), grad_sync=sync)     # same PCGrad task order on every rank
+                        shuffle_rng=random.Random(seed), grad_sync=sync, rng_mode=a.rng)     # same PCGrad task order on every rank
     temperature = TemperatureScheduler(total_steps=462 * PT.EPOCHS)
     pool = make_pool(seed + 1000 * rank, device, engine.dpad)   # every rank draws its own batches (weak scaling)
     gen = torch.Generator().manual_seed(seed + rank)
@@ -198,7 +202,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
-                       "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}"},
+                       "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "index_rng": a.rng},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -33,7 +33,7 @@ from .constants import DOMAIN_DIMENSIONS, GRAPH_PROPERTY_DIM
 from .graph import Batch
 from .models.gnn import DROPOUT_RATE, GNN_HIDDEN_DIM, GNN_NUM_LAYERS
 from .models.pretrain_model import PretrainableGNN, draw_mask_indices
-from .pretrain.augmentations import GraphAugmentor, _augment_one, common_masks
+from .pretrain.augmentations import _augment_one
 from .pretrain.control import DEFAULT_LR, DEFAULT_WEIGHT_DECAY, TASK_SPECIFIC_LR
 from .pretrain.tasks import sample_negative_edges
 
@@ -77,10 +77,24 @@ class StepPlan:
     pass
 
 
+class ViewArrays:
+    """One augmented view of a whole domain batch as flat index arrays (what Batch.from_data_list of the
+    augmented graphs would hold, minus the features): rows = kept nodes (domain-local ids of the base batch),
+    edges = [2, e'] in view-local numbering, ptr = per-graph node offsets, rowmask = per-row bitmask of zeroed
+    feature columns (None if no graph drew an attribute mask), common = view-local ids of nodes kept in BOTH views."""
+    __slots__ = ("rows", "edges", "ptr", "rowmask", "common")
+
+    def __init__(self, rows, edges, ptr, rowmask, common) -> None:
+        self.rows, self.edges, self.ptr, self.rowmask, self.common = rows, edges, ptr, rowmask, common
+
+
 class StepEngine:
     def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
-                 grad_sync=None) -> None:
+                 grad_sync=None, rng_mode: str = "reference") -> None:
+        if rng_mode not in ("reference", "vectorized"):
+            raise ValueError("rng_mode must be 'reference' or 'vectorized'")
+        self.rng_mode, self._nprng = rng_mode, None
         for t in tasks:
             if t not in SUPPORTED_TASKS:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
@@ -229,119 +243,274 @@ class StepEngine:
         self.dev32 = torch.empty(self.i32_cap, dtype=torch.int32, device=dev)
         self.dev64 = torch.empty(self.i64_cap, dtype=torch.int64, device=dev)
 
-    # ------------------------------------------------------------------ host: plan one step
+    # ------------------------------------------------------------------ host: draw + plan one step
     def draw(self, inp: StepInputs, gen: torch.Generator) -> Dict[str, object]:
-        """All RNG of one step, in the reference's order (tasks in ACTIVE_TASKS order, domains in dict order)."""
+        """All RNG of one step as index arrays, tasks in ACTIVE_TASKS order, domains in dict order.
+        rng_mode 'reference': the reference's exact draw sequence from the caller's CPU torch.Generator (bit-identical
+        indices for an equal generator state; per-graph Python loop).  rng_mode 'vectorized': the same distributions
+        drawn for all graphs of a domain at once with numpy (different stream, ~10x less host time)."""
+        if self.rng_mode == "vectorized":
+            return self._draw_vectorized(inp, gen)
         art: Dict[str, object] = {}
         host = {d: inp.host[d] for d in self.domains}
         for t in self.tasks:
             if t == "node_feat_mask":
-                art[t] = {d: draw_mask_indices(b.ptr_host, gen) for d, b in host.items()}
+                art[t] = {d: draw_mask_indices(b.ptr_host, gen).numpy() for d, b in host.items()}
             elif t == "link_pred":
-                art[t] = {d: sample_negative_edges(b, gen) for d, b in host.items()}
+                art[t] = {d: sample_negative_edges(b, gen).numpy() for d, b in host.items()}
             elif t in ("node_contrast", "graph_contrast"):
                 art[t] = {d: (self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
                           for d, b in host.items()}
         return art
 
     @staticmethod
-    def _draw_views(b: Batch, gen: torch.Generator):
-        """Same draws as GraphAugmentor.create_two_views, kept as index arrays (no feature copies)."""
+    def _draw_views(b: Batch, gen: torch.Generator) -> Tuple[ViewArrays, ViewArrays]:
+        """Same draws as GraphAugmentor.create_two_views (augmentations.py:88-111), kept as index arrays."""
         ei = b.edge_index.numpy()
         F = b.x.size(1)
-        out = []
+        acc = [dict(rows=[], edges=[], ptr=[0], masks=[], common=[]) for _ in range(2)]
         for g in range(b.num_graphs):
             s, e = b.ptr_host[g], b.ptr_host[g + 1]
             es, ee = b.edge_ptr_host[g], b.edge_ptr_host[g + 1]
             loc = ei[:, es:ee] - s
-            v1 = _augment_one(e - s, loc, F, gen)
-            v2 = _augment_one(e - s, loc, F, gen)
-            out.append((v1, v2))
-        return out
+            pair = (_augment_one(e - s, loc, F, gen), _augment_one(e - s, loc, F, gen))
+            flags = np.zeros((2, e - s), dtype=bool)
+            flags[0, pair[0].kept] = True
+            flags[1, pair[1].kept] = True
+            for vi, v in enumerate(pair):
+                a = acc[vi]
+                base = a["ptr"][-1]
+                a["rows"].append(v.kept + s)
+                a["edges"].append(v.edges + base)
+                a["common"].append(np.flatnonzero(flags[1 - vi, v.kept]) + base)
+                m = 0
+                if v.masked_cols is not None:
+                    for c in v.masked_cols:
+                        m |= 1 << int(c)
+                a["masks"].append(np.full(len(v.kept), m, dtype=np.uint64))
+                a["ptr"].append(base + len(v.kept))
+        out = []
+        for a in acc:
+            rm = np.concatenate(a["masks"])
+            out.append(ViewArrays(np.concatenate(a["rows"]), np.concatenate(a["edges"], axis=1), np.asarray(a["ptr"], dtype=np.int64),
+                                  rm if rm.any() else None, np.concatenate(a["common"])))
+        return out[0], out[1]
 
+    # ---- vectorized draws (same distributions, numpy stream) --------------------------------------------
+    def _np_rng(self, gen: torch.Generator) -> np.random.Generator:
+        if self._nprng is None:
+            self._nprng = np.random.default_rng(int(torch.randint(0, 2 ** 62, (1,), generator=gen).item()))
+        return self._nprng
+
+    @staticmethod
+    def _rank_in_group(keys: np.ndarray, group: np.ndarray, gptr: np.ndarray) -> np.ndarray:
+        """rank of every element among the elements of its group when ordered by key (groups are contiguous)."""
+        order = np.argsort(group + keys)          # keys in [0,1): one float sort orders by (group, key)
+        rank = np.empty(len(keys), dtype=np.int64)
+        rank[order] = np.arange(len(keys)) - gptr[group[order]]
+        return rank
+
+    def _static(self, inp: StepInputs, d: str) -> Dict[str, np.ndarray]:
+        """Per-input structures that do not depend on the step's RNG (cached on the StepInputs)."""
+        cache = inp.__dict__.setdefault("_static", {})
+        if d not in cache:
+            hb = inp.host[d]
+            ptr = np.asarray(hb.ptr_host, dtype=np.int64)
+            n = np.diff(ptr)
+            ei = hb.edge_index.numpy()
+            eptr = np.asarray(hb.edge_ptr_host, dtype=np.int64)
+            st = {"ptr": ptr, "n": n, "node_graph": np.repeat(np.arange(len(n)), n), "ei": ei, "eptr": eptr,
+                  "edge_graph": np.repeat(np.arange(len(n)), np.diff(eptr)), "F": hb.x.size(1)}
+            # candidate negative edges: ordered pairs (i, j), i != j, not adjacent in either direction
+            cs, cd, cg = [], [], []
+            for g in range(len(n)):
+                adj = np.zeros((n[g], n[g]), dtype=bool)
+                loc = ei[:, eptr[g]:eptr[g + 1]] - ptr[g]
+                adj[loc[0], loc[1]] = True
+                adj[loc[1], loc[0]] = True
+                np.fill_diagonal(adj, True)
+                i, j = np.nonzero(~adj)
+                cs.append(i + ptr[g]); cd.append(j + ptr[g]); cg.append(np.full(len(i), g))
+            st["cand"] = np.stack([np.concatenate(cs), np.concatenate(cd)])
+            st["cand_graph"] = np.concatenate(cg)
+            st["cand_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(st["cand_graph"], minlength=len(n)))])
+            cache[d] = st
+        return cache[d]
+
+    def _view_vectorized(self, st, rng: np.random.Generator, keep: np.ndarray) -> Tuple[np.ndarray, ...]:
+        """Edge drop + attribute mask for one view of a whole domain batch, given its node keep mask."""
+        new_id = np.cumsum(keep) - 1
+        rows = np.flatnonzero(keep)
+        ei, eg = st["ei"], st["edge_graph"]
+        em = keep[ei[0]] & keep[ei[1]]
+        edges = new_id[ei[:, em]]
+        eg = eg[em]
+        G = len(st["n"])
+        ecount = np.bincount(eg, minlength=G)
+        coin = (rng.random(G) < 0.2) & (ecount >= 3)
+        if coin.any():
+            eptr = np.concatenate([[0], np.cumsum(ecount)])
+            rank = self._rank_in_group(rng.random(len(eg)), eg, eptr)
+            keep_e = ecount - np.maximum(1, (ecount * 0.2).astype(np.int64))
+            ekeep = ~coin[eg] | (rank < keep_e[eg])
+            edges = edges[:, ekeep]
+        kept_n = np.bincount(st["node_graph"][keep], minlength=G)
+        ptr = np.concatenate([[0], np.cumsum(kept_n)])
+        rowmask = None
+        F = st["F"]
+        coin2 = rng.random(G) < 0.2
+        if F >= 3 and coin2.any():
+            m = max(1, int(F * 0.2))
+            cols = np.argsort(rng.random((G, F)), axis=1)[:, :m]
+            bits = np.bitwise_or.reduce(np.uint64(1) << cols.astype(np.uint64), axis=1)
+            bits[~coin2] = 0
+            rowmask = np.repeat(bits, kept_n)
+        return rows, edges, ptr, rowmask, new_id
+
+    def _draw_vectorized(self, inp: StepInputs, gen: torch.Generator) -> Dict[str, object]:
+        rng = self._np_rng(gen)
+        art: Dict[str, object] = {}
+        for t in self.tasks:
+            if t == "graph_prop":
+                continue
+            out = art[t] = {}
+            for d in self.domains:
+                st = self._static(inp, d)
+                n, ng, ptr = st["n"], st["node_graph"], st["ptr"]
+                if t == "node_feat_mask":
+                    k = np.where(n >= 3, np.maximum(1, (n * 0.15).astype(np.int64)), 0)
+                    rank = self._rank_in_group(rng.random(len(ng)), ng, ptr)
+                    out[d] = np.flatnonzero(rank < k[ng])
+                elif t == "link_pred":
+                    cptr = st["cand_ptr"]
+                    want = np.minimum(np.diff(st["eptr"]), np.diff(cptr))
+                    pick = [cptr[g] + rng.choice(cptr[g + 1] - cptr[g], size=want[g], replace=False)
+                            for g in range(len(n)) if want[g] > 0]
+                    out[d] = st["cand"][:, np.concatenate(pick)] if pick else np.zeros((2, 0), dtype=np.int64)
+                else:
+                    if t == "graph_contrast" and len(n) < 2:
+                        out[d] = None
+                        continue
+                    keep_n = np.where(n >= 3, n - np.maximum(1, (n * 0.2).astype(np.int64)), n)
+                    keeps = [self._rank_in_group(rng.random(len(ng)), ng, ptr) < keep_n[ng] for _ in range(2)]
+                    parts = [self._view_vectorized(st, rng, k) for k in keeps]
+                    both = keeps[0] & keeps[1]
+                    out[d] = tuple(ViewArrays(rows, edges, vptr, rowmask, new_id[both]) for (rows, edges, vptr, rowmask, new_id) in parts)
+        return art
+
+    # ---- plan: lay the step out as segments, everything as flat arrays ----------------------------------
     def plan(self, inp: StepInputs, art: Dict[str, object]) -> StepPlan:
-        p = StepPlan()
-        D = self.domains
-        seg_ptr, seg_dom, seg_task, seg_mask = [0], [], [], []
-        src_rows: List[np.ndarray] = []
-        edges: List[np.ndarray] = []
+        p, D = StepPlan(), self.domains
+        seg_ptr, seg_dom, seg_task = [0], [], []
+        src_rows, edges, rowmasks = [], [], []
         task_row = [0]
-        p.info = {}
+        a32: Dict[str, np.ndarray] = {}
+        a64: Dict[str, np.ndarray] = {}
+        sizes: Dict[str, int] = {}
+        p.skipped = []
 
-        def add_segment(task_i: int, dom_i: int, rows: np.ndarray, e_local: np.ndarray, colmask: int = 0) -> int:
+        def add_segment(ti: int, di: int, rows: np.ndarray, e_local: np.ndarray, rowmask: Optional[np.ndarray]) -> int:
             r0 = seg_ptr[-1]
-            src_rows.append(rows.astype(np.int32))
-            edges.append(e_local.astype(np.int64) + r0)
-            seg_ptr.append(r0 + len(rows)); seg_dom.append(dom_i); seg_task.append(task_i); seg_mask.append(colmask)
+            src_rows.append(rows)
+            edges.append(e_local + r0)
+            rowmasks.append((r0, rowmask))
+            seg_ptr.append(r0 + len(rows)); seg_dom.append(di); seg_task.append(ti)
             return r0
 
-        def view_mask(v) -> int:
-            m = 0
-            if v.masked_cols is not None:
-                for c in v.masked_cols:
-                    m |= 1 << int(c)
-            return m
-
         for ti, t in enumerate(self.tasks):
-            info = p.info[t] = {}
-            for di, d in enumerate(D):
-                hb, roff = inp.host[d], inp.row_off[d]
-                base_rows = np.arange(roff, roff + hb.num_nodes)
-                if t in ("node_feat_mask", "link_pred", "graph_prop"):
-                    r0 = add_segment(ti, di, base_rows, hb.edge_index.numpy())
-                    info[d] = {"r0": r0, "n": hb.num_nodes, "ptr": [r0 + v for v in hb.ptr_host]}
+            if t in ("node_feat_mask", "link_pred", "graph_prop"):
+                r0s = []
+                for di, d in enumerate(D):
+                    hb, roff = inp.host[d], inp.row_off[d]
+                    r0s.append(add_segment(ti, di, np.arange(roff, roff + hb.num_nodes), hb.edge_index.numpy(), None))
+                if t == "node_feat_mask":
+                    idx = [np.asarray(art[t][d], dtype=np.int64) + r0 for d, r0 in zip(D, r0s)]
+                    rows = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).tolist()
+                    p.skipped += [(ti, d) for d, i in zip(D, idx) if len(i) == 0]
+                    a64["nfm_idx"] = np.concatenate(idx)
+                    p.nfm_rows = rows
+                    sizes[t] = rows[-1] * H
+                elif t == "link_pred":
+                    eds, npos = [], []
+                    for d, r0 in zip(D, r0s):
+                        pos = inp.host[d].edge_index.numpy() + r0
+                        eds += [pos, np.asarray(art[t][d], dtype=np.int64) + r0]
+                        npos.append((pos.shape[1], eds[-1].shape[1]))
+                    e = np.concatenate(eds, axis=1)
+                    lab = np.concatenate([np.concatenate([np.ones(a, dtype=np.float32), np.zeros(b, dtype=np.float32)]) for a, b in npos])
+                    if e.shape[1] > self.KMAX:
+                        raise L.GnnmpError("engine: too many link-prediction edges")
+                    a64["lp_edges"] = e
+                    p.lp_labels, p.lp_K = lab, e.shape[1]
+                    sizes[t] = e.shape[1]
                 else:
-                    views = art[t][d]
+                    starts, rows = [], [0]
+                    for d, r0 in zip(D, r0s):
+                        ph = inp.host[d].ptr_host
+                        starts += [r0 + v for v in ph[:-1]]
+                        rows.append(rows[-1] + len(ph) - 1)
+                    end = seg_ptr[-1]
+                    ptr = np.asarray(starts + [end], dtype=np.int64)
+                    a32["gp_ptr"] = ptr
+                    a64["gp_gid"] = np.repeat(np.arange(len(starts)), np.diff(ptr))
+                    p.gp_rows, p.gp_B, p.gp_r0, p.gp_M = rows, len(starts), task_row[-1], end - task_row[-1]
+                    sizes[t] = rows[-1] * GRAPH_PROPERTY_DIM
+            else:
+                idx, rows, ns, starts = [], [0], [], []
+                for di, d in enumerate(D):
+                    views, roff = art[t][d], inp.row_off[d]
                     if views is None:
-                        info[d] = None
+                        ns.append(0); rows.append(rows[-1]); p.skipped.append((ti, d))
                         continue
-                    per_view = []
-                    for vi in (0, 1):
-                        n_acc, rows, eds, ptr, commons = 0, [], [], [0], []
-                        for g, pair in enumerate(views):
-                            v = pair[vi]
-                            rows.append(v.kept + roff + hb.ptr_host[g])
-                            eds.append(v.edges + n_acc)
-                            other = pair[1 - vi]
-                            commons.append(np.flatnonzero(np.isin(v.kept, other.kept)) + n_acc)
-                            n_acc += len(v.kept)
-                            ptr.append(n_acc)
-                        # one column mask per SEGMENT is not enough: the attribute mask is per graph -> split
-                        # a view into runs of graphs with the same mask (almost always a single run)
-                        masks = [view_mask(pair[vi]) for pair in views]
-                        per_view.append((np.concatenate(rows), np.concatenate(eds, axis=1), ptr, np.concatenate(commons), masks))
-                    info[d] = {"views": []}
-                    for rows, eds, ptr, common, masks in per_view:
-                        r0 = add_segment(ti, di, rows, eds, 0)
-                        info[d]["views"].append({"r0": r0, "n": len(rows), "ptr": [r0 + v for v in ptr], "common": common + r0,
-                                                 "graph_masks": masks})
+                    r0s = [add_segment(ti, di, v.rows + roff, v.edges, v.rowmask) for v in views]
+                    if t == "node_contrast":
+                        c1, c2 = views[0].common, views[1].common
+                        n = len(c1) if (len(c1) >= 2 and len(c2) >= 2) else 0        # tasks.py:171-173
+                        ns.append(n)
+                        if n:
+                            idx += [c1 + r0s[0], c2 + r0s[1]]
+                        else:
+                            p.skipped.append((ti, d))
+                        rows.append(rows[-1] + 2 * n)
+                    else:
+                        for v, r0 in zip(views, r0s):
+                            starts.append(v.ptr[:-1] + r0)
+                        B = len(views[0].ptr) - 1
+                        ns.append(B); rows.append(rows[-1] + 2 * B)
+                if t == "node_contrast":
+                    a64["nc_idx"] = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64)
+                    p.nc_rows, p.nc_n = rows, ns
+                else:
+                    st = np.concatenate(starts) if starts else np.zeros(0, dtype=np.int64)
+                    ptr = np.concatenate([st, [seg_ptr[-1]]])
+                    a32["gc_ptr"] = ptr
+                    a64["gc_gid"] = np.repeat(np.arange(len(st)), np.diff(ptr))
+                    p.gc_rows, p.gc_n, p.gc_B, p.gc_r0, p.gc_M = rows, ns, len(st), task_row[-1], seg_ptr[-1] - task_row[-1]
+                sizes[t] = rows[-1]
             task_row.append(seg_ptr[-1])
-        p.seg_ptr, p.seg_dom, p.seg_task, p.task_row = seg_ptr, seg_dom, seg_task, task_row
-        p.N = seg_ptr[-1]
-        p.S = len(seg_dom)
-        p.src_row = np.concatenate(src_rows)
-        p.edge_index = np.concatenate(edges, axis=1)
-        p.E = p.edge_index.shape[1]
+        p.seg_ptr, p.seg_dom, p.seg_task, p.task_row, p.sizes = seg_ptr, seg_dom, seg_task, task_row, sizes
+        p.N, p.S = seg_ptr[-1], len(seg_dom)
+        e_all = np.concatenate(edges, axis=1)
+        p.E = e_all.shape[1]
         p.max_seg = max(b - a for a, b in zip(seg_ptr[:-1], seg_ptr[1:]))
-        # per-row attribute masks: rows whose graph drew an attribute mask get their own feature bitmask
-        rowmask = np.zeros(p.N, dtype=np.uint64)
-        any_mask = False
-        for t in self.tasks:
-            if t not in ("node_contrast", "graph_contrast"):
-                continue
-            for d in D:
-                inf = p.info[t][d]
-                if inf is None:
-                    continue
-                for v in inf["views"]:
-                    for g, m in enumerate(v["graph_masks"]):
-                        if m:
-                            rowmask[v["ptr"][g]:v["ptr"][g + 1]] = np.uint64(m)
-                            any_mask = True
-        p.rowmask = rowmask if any_mask else None
         if p.N > self.max_rows or p.E > self.max_edges or p.S > self.S_MAX:
             raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
                                f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
+        a32["seg_ptr"], a32["seg_dom"], a32["src_row"] = np.asarray(seg_ptr), np.asarray(seg_dom), np.concatenate(src_rows)
+        nt = [(b - a + 31) // 32 for a, b in zip(seg_ptr[:-1], seg_ptr[1:])]
+        tile_seg = np.repeat(np.arange(p.S), nt)
+        tile_first = np.concatenate([[0], np.cumsum(nt)])[:-1]
+        tile_row = np.asarray(seg_ptr[:-1])[tile_seg] + 32 * (np.arange(len(tile_seg)) - tile_first[tile_seg])
+        a32["tiles"] = np.stack([tile_seg, tile_row], axis=1)
+        p.num_tiles = len(tile_seg)
+        a64["edge_index"] = e_all
+        if any(m is not None for _, m in rowmasks):
+            rm = np.zeros(p.N, dtype=np.uint64)
+            for r0, m in rowmasks:
+                if m is not None:
+                    rm[r0:r0 + len(m)] = m
+            a64["rowmask"] = rm.view(np.int64)
+        p.a32, p.a64 = a32, a64
         return p
 
     # ------------------------------------------------------------------ device helpers
@@ -383,120 +552,37 @@ class StepEngine:
 
     # ---- upload ------------------------------------------------------------------------------------
     def _upload(self, p: StepPlan, inp: StepInputs, art) -> None:
-        lay32, lay64 = {}, {}
-        cur = {"o32": 0, "o64": 0}
         slot = self.stage[self.step_count % self.STAGES]
         if slot["event"] is not None:
             slot["event"].synchronize()                  # the copy that read this slot STAGES steps ago is done
-        self.pin32, self.pin64, self.pinf = slot["pin32"], slot["pin64"], slot["pinf"]
-
-        def put32(name: str, arr) -> None:
-            a = np.ascontiguousarray(np.asarray(arr, dtype=np.int32).reshape(-1))
-            o = cur["o32"]
-            if o + a.size > self.i32_cap:
+        pin32, pin64, pinf = slot["pin32"], slot["pin64"], slot["pinf"]
+        n32, n64 = pin32.numpy(), pin64.numpy()
+        o32 = o64 = 0
+        lay32, lay64 = {}, {}
+        for name, arr in p.a32.items():
+            a = np.asarray(arr).reshape(-1)
+            if o32 + a.size > self.i32_cap:
                 raise L.GnnmpError("engine: int32 staging buffer too small")
-            self.pin32[o:o + a.size] = torch.from_numpy(a)
-            lay32[name] = o
-            cur["o32"] = o + (a.size + 3) // 4 * 4
-
-        def put64(name: str, arr) -> None:
-            a = np.ascontiguousarray(np.asarray(arr, dtype=np.int64).reshape(-1))
-            o = cur["o64"]
-            if o + a.size > self.i64_cap:
+            n32[o32:o32 + a.size] = a
+            lay32[name] = o32
+            o32 += (a.size + 3) // 4 * 4
+        for name, arr in p.a64.items():
+            a = np.asarray(arr).reshape(-1)
+            if o64 + a.size > self.i64_cap:
                 raise L.GnnmpError("engine: int64 staging buffer too small")
-            self.pin64[o:o + a.size] = torch.from_numpy(a)
-            lay64[name] = o
-            cur["o64"] = o + (a.size + 1) // 2 * 2
-
-        put32("seg_ptr", p.seg_ptr); put32("seg_dom", p.seg_dom); put32("src_row", p.src_row)
-        tiles = [(s, r) for s in range(p.S) for r in range(p.seg_ptr[s], p.seg_ptr[s + 1], 32)]
-        p.num_tiles = len(tiles)
-        put32("tiles", tiles)
-        put64("edge_index", p.edge_index)
-        if p.rowmask is not None:
-            put64("rowmask", p.rowmask.view(np.int64))
-        sizes, D = {}, self.domains
-        p.skipped = []                       # (task index, domain) pairs that contribute nothing this step
+            n64[o64:o64 + a.size] = a
+            lay64[name] = o64
+            o64 += (a.size + 1) // 2 * 2
+        self.dev32[:o32].copy_(pin32[:o32], non_blocking=True)
+        self.dev64[:o64].copy_(pin64[:o64], non_blocking=True)
+        nf = pinf.numpy()
+        nf[:64] = 0.0
         for ti, t in enumerate(self.tasks):
-            info = p.info[t]
-            if t == "node_feat_mask":
-                idx, rows = [], [0]
-                for d in D:
-                    idx.append(art[t][d].numpy() + info[d]["r0"])
-                    rows.append(rows[-1] + len(idx[-1]))
-                    if len(idx[-1]) == 0:
-                        p.skipped.append((ti, d))
-                put64("nfm_idx", np.concatenate(idx))
-                p.nfm_rows = rows
-                sizes[t] = rows[-1] * H
-            elif t == "link_pred":
-                eds, ks, npos = [], [0], []
-                for d in D:
-                    pos = inp.host[d].edge_index.numpy() + info[d]["r0"]
-                    neg = art[t][d].numpy() + info[d]["r0"]
-                    eds.append(np.concatenate([pos, neg], axis=1))
-                    ks.append(ks[-1] + eds[-1].shape[1]); npos.append(pos.shape[1])
-                e = np.concatenate(eds, axis=1)
-                if e.shape[1] > self.KMAX:
-                    raise L.GnnmpError("engine: too many link-prediction edges")
-                put64("lp_edges", e)
-                lab = np.zeros(e.shape[1], dtype=np.float32)
-                for i in range(len(D)):
-                    lab[ks[i]:ks[i] + npos[i]] = 1.0
-                p.lp_labels, p.lp_K = lab, e.shape[1]
-                sizes[t] = e.shape[1]
-            elif t == "node_contrast":
-                idx, rows, ns = [], [0], []
-                for d in D:
-                    c1, c2 = info[d]["views"][0]["common"], info[d]["views"][1]["common"]
-                    n = len(c1) if (len(c1) >= 2 and len(c2) >= 2) else 0       # tasks.py:171-173
-                    ns.append(n)
-                    if n:
-                        idx += [c1, c2]
-                    else:
-                        p.skipped.append((ti, d))
-                    rows.append(rows[-1] + 2 * n)
-                put64("nc_idx", np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64))
-                p.nc_rows, p.nc_n = rows, ns
-                sizes[t] = rows[-1]
-            elif t == "graph_contrast":
-                starts, rows, ns = [], [0], []
-                for d in D:
-                    inf = info[d]
-                    if inf is None:
-                        ns.append(0); rows.append(rows[-1]); p.skipped.append((ti, d))
-                        continue
-                    for v in inf["views"]:
-                        starts += v["ptr"][:-1]
-                    B = len(inf["views"][0]["ptr"]) - 1
-                    ns.append(B); rows.append(rows[-1] + 2 * B)
-                ptr = np.asarray(starts + [p.task_row[ti + 1]], dtype=np.int64)
-                put32("gc_ptr", ptr)
-                put64("gc_gid", np.repeat(np.arange(len(starts)), np.diff(ptr)))
-                p.gc_rows, p.gc_n, p.gc_B, p.gc_r0, p.gc_M = rows, ns, len(starts), p.task_row[ti], p.task_row[ti + 1] - p.task_row[ti]
-                sizes[t] = rows[-1]
-            elif t == "graph_prop":
-                starts, rows = [], [0]
-                for d in D:
-                    pr = info[d]["ptr"]
-                    starts += pr[:-1]
-                    rows.append(rows[-1] + len(pr) - 1)
-                ptr = np.asarray(starts + [p.task_row[ti + 1]], dtype=np.int64)
-                put32("gp_ptr", ptr)
-                put64("gp_gid", np.repeat(np.arange(len(starts)), np.diff(ptr)))
-                p.gp_rows, p.gp_B, p.gp_r0, p.gp_M = rows, len(starts), p.task_row[ti], p.task_row[ti + 1] - p.task_row[ti]
-                sizes[t] = rows[-1] * GRAPH_PROPERTY_DIM
-        p.sizes = sizes
-        o32, o64 = cur["o32"], cur["o64"]
-        self.dev32[:o32].copy_(self.pin32[:o32], non_blocking=True)
-        self.dev64[:o64].copy_(self.pin64[:o64], non_blocking=True)
-        self.pinf[:64].zero_()
-        for ti, t in enumerate(self.tasks):
-            self.pinf[ti] = 1.0 / max(sizes[t], 1)
-        self.scal.copy_(self.pinf[:64], non_blocking=True)     # [0:8) = 1/size per task, [16:48) = per-domain NT-Xent sums (zeroed)
+            nf[ti] = 1.0 / max(p.sizes[t], 1)
+        self.scal.copy_(pinf[:64], non_blocking=True)     # [0:8) = 1/size per task, [16:48) = per-domain NT-Xent sums (zeroed)
         if "link_pred" in self.tasks:
-            self.pinf[64:64 + p.lp_K] = torch.from_numpy(p.lp_labels)
-            self.lp_lab[:p.lp_K].copy_(self.pinf[64:64 + p.lp_K], non_blocking=True)
+            nf[64:64 + p.lp_K] = p.lp_labels
+            self.lp_lab[:p.lp_K].copy_(pinf[64:64 + p.lp_K], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         slot["event"] = ev

@@ -14,7 +14,6 @@ from gnn_pretraining_amd import synthetic as S                                  
 from gnn_pretraining_amd.engine import StepEngine, StepInputs                      # noqa: E402
 from gnn_pretraining_amd.models import PretrainableGNN                             # noqa: E402
 from gnn_pretraining_amd.pretrain import pretrain as PT                            # noqa: E402
-from gnn_pretraining_amd.pretrain.augmentations import _assemble                   # noqa: E402
 from oracle import models as OM, tasks as OTk, train as OTr                        # noqa: E402
 from parity_util import assert_close, assert_grad_close, copy_state, set_dropout, to_oracle   # noqa: E402
 from test_gpu_modules import perturb_bn                                            # noqa: E402
@@ -22,7 +21,7 @@ from test_gpu_modules import perturb_bn                                         
 DEV = torch.device("cuda:0")
 
 
-def build(scheme, seed):
+def build(scheme, seed, rng_mode="reference"):
     tasks, domains = PT.ACTIVE_TASKS[scheme], PT.PRETRAIN_DOMAINS[scheme]
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
@@ -36,11 +35,27 @@ def build(scheme, seed):
     hm.to(DEV)
     set_dropout(om, 0.0)
     om.train(); hm.train()
-    eng = StepEngine(hm, tasks, domains, DEV, seed=seed)
+    eng = StepEngine(hm, tasks, domains, DEV, seed=seed, rng_mode=rng_mode)
     eng.dropout_p = 0.0
     host = S.pretrain_step_batches(gen, domains)
     inp = StepInputs(host, DEV, eng.dpad)
     return om, hm, eng, host, inp, gen, tasks, domains
+
+
+def view_to_oracle(host_batch, v):
+    """ViewArrays -> the oracle's Batch of augmented graphs (features gathered and attribute-masked on the host)."""
+    from oracle import graph_ops as OG
+    rows = torch.from_numpy(np.asarray(v.rows, dtype=np.int64))
+    x = host_batch.x[rows].clone()
+    if v.rowmask is not None:
+        F = x.size(1)
+        bits = ((v.rowmask[:, None] >> np.arange(F, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        x[torch.from_numpy(bits)] = 0.0
+    ptr = torch.from_numpy(np.asarray(v.ptr, dtype=np.int64))
+    batch = torch.repeat_interleave(torch.arange(len(ptr) - 1), ptr[1:] - ptr[:-1])
+    ei = torch.from_numpy(np.asarray(v.edges, dtype=np.int64))
+    eptr = torch.zeros(len(ptr), dtype=torch.long)      # not used by the oracle losses
+    return OG.Batch(x, ei, batch, ptr, eptr, host_batch.y, host_batch.graph_properties)
 
 
 def oracle_artefacts(art, host):
@@ -48,24 +63,24 @@ def oracle_artefacts(art, host):
     for t, a in art.items():
         if t in ("node_contrast", "graph_contrast"):
             conv = {}
-            for d, pairs in a.items():
-                if pairs is None:
+            for d, views in a.items():
+                if views is None:
                     conv[d] = None
                     continue
-                v1 = _assemble(host[d], [p[0] for p in pairs], None)
-                v2 = _assemble(host[d], [p[1] for p in pairs], None)
-                c1 = torch.from_numpy(np.concatenate([np.isin(p[0].kept, p[1].kept) for p in pairs]))
-                c2 = torch.from_numpy(np.concatenate([np.isin(p[1].kept, p[0].kept) for p in pairs]))
-                conv[d] = OTk.TwoViews(to_oracle(v1), to_oracle(v2), c1, c2)
+                b1, b2 = view_to_oracle(host[d], views[0]), view_to_oracle(host[d], views[1])
+                c1 = torch.zeros(b1.num_nodes, dtype=torch.bool); c1[torch.from_numpy(views[0].common)] = True
+                c2 = torch.zeros(b2.num_nodes, dtype=torch.bool); c2[torch.from_numpy(views[1].common)] = True
+                conv[d] = OTk.TwoViews(b1, b2, c1, c2)
             out[t] = conv
         else:
-            out[t] = a
+            out[t] = {d: torch.from_numpy(np.asarray(v, dtype=np.int64)) for d, v in a.items()}
     return out
 
 
-@pytest.mark.parametrize("scheme,seed", [("s4", 41), ("b2", 42), ("s2", 43), ("b4", 44)])
-def test_engine_losses_task_gradients_and_running_stats(scheme, seed):
-    om, hm, eng, host, inp, gen, tasks, domains = build(scheme, seed)
+@pytest.mark.parametrize("scheme,seed,rng_mode", [("s4", 41, "reference"), ("b2", 42, "reference"), ("s2", 43, "reference"),
+                                                  ("b4", 44, "reference"), ("s4", 45, "vectorized"), ("s3", 46, "vectorized")])
+def test_engine_losses_task_gradients_and_running_stats(scheme, seed, rng_mode):
+    om, hm, eng, host, inp, gen, tasks, domains = build(scheme, seed, rng_mode)
     art = eng.draw(inp, gen)
     eng.temperature = 0.37
     eng.step(inp, gen, art=art, order=list(tasks), apply_update=False)

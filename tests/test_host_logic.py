@@ -46,3 +46,104 @@ def test_mask_indices_bit_exact_vs_oracle():
     b = S.domain_batch(gen, 21, 8)
     g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
     assert torch.equal(draw_mask_indices(b.ptr_host, g1), OraclePG.draw_mask_indices(b.ptr, g2))
+
+
+# ---------------------------------------------------------------- engine host planning (no GPU involved)
+import numpy as np                                                        # noqa: E402
+from gnn_pretraining_amd.engine import StepEngine                          # noqa: E402
+from gnn_pretraining_amd.pretrain import pretrain as PT                    # noqa: E402
+
+
+class _Inp:
+    def __init__(self, host):
+        self.host, self.domains, self.row_off, r = host, list(host), {}, 0
+        for d in host:
+            self.row_off[d] = r
+            r += host[d].num_nodes
+
+
+def _planner(mode, scheme="s4"):
+    e = StepEngine.__new__(StepEngine)                # host-side methods only: no device, no library
+    e.tasks, e.domains = PT.ACTIVE_TASKS[scheme], PT.PRETRAIN_DOMAINS[scheme]
+    e.max_rows, e.max_edges, e.S_MAX, e.KMAX, e.rng_mode, e._nprng = 16384, 131072, 64, 131072, mode, None
+    return e
+
+
+def test_reference_mode_views_equal_oracle_views():
+    """Engine index artefacts == what the oracle's create_two_views builds, for an equal generator state."""
+    gen = torch.Generator().manual_seed(3)
+    host = S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"])
+    for d, b in host.items():
+        g1, g2 = torch.Generator().manual_seed(17), torch.Generator().manual_seed(17)
+        v1, v2 = StepEngine._draw_views(b, g1)
+        o1, o2, m1, m2 = OA.create_two_views(to_oracle(b), g2)
+        for v, o, m in ((v1, o1, m1), (v2, o2, m2)):
+            x = b.x[torch.from_numpy(v.rows)].clone()
+            if v.rowmask is not None:
+                F = x.size(1)
+                bits = ((v.rowmask[:, None] >> np.arange(F, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+                x[torch.from_numpy(bits)] = 0.0
+            assert torch.equal(x, o.x)
+            assert torch.equal(torch.from_numpy(v.edges), o.edge_index)
+            assert torch.equal(torch.from_numpy(v.ptr), o.ptr)
+            assert torch.equal(torch.from_numpy(v.common), torch.cat(m).nonzero().squeeze(1))
+
+
+def test_vectorized_draws_are_valid_artefacts():
+    """The vectorized sampler draws from the same distributions: every structural rule of the reference holds."""
+    gen = torch.Generator().manual_seed(5)
+    host = S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"])
+    e, inp = _planner("vectorized"), _Inp(host)
+    saw_edge_drop = saw_attr_mask = False
+    for _ in range(12):
+        art = e.draw(inp, gen)
+        for d, b in host.items():
+            n = np.diff(np.asarray(b.ptr_host)); ei = b.edge_index.numpy()
+            # NFM: max(1, int(.15 n)) distinct nodes per graph with n >= 3
+            idx = art["node_feat_mask"][d]
+            per = np.bincount(np.searchsorted(np.asarray(b.ptr_host), idx, side="right") - 1, minlength=len(n))
+            assert len(np.unique(idx)) == len(idx)
+            assert np.array_equal(per, np.where(n >= 3, np.maximum(1, (n * .15).astype(int)), 0))
+            # LP: as many negatives as directed edges per graph, all non-adjacent ordered pairs inside the graph
+            neg = art["link_pred"][d]
+            g_of = lambda v: np.searchsorted(np.asarray(b.ptr_host), v, side="right") - 1
+            assert np.array_equal(g_of(neg[0]), g_of(neg[1])) and (neg[0] != neg[1]).all()
+            assert np.array_equal(np.bincount(g_of(neg[0]), minlength=len(n)), np.diff(np.asarray(b.edge_ptr_host)))
+            und = set(map(tuple, ei.T)) | set(map(tuple, ei[::-1].T))
+            assert not (set(map(tuple, neg.T)) & und) and len(set(map(tuple, neg.T))) == neg.shape[1]
+            for t in ("node_contrast", "graph_contrast"):
+                v1, v2 = art[t][d]
+                for v in (v1, v2):
+                    kept = np.diff(v.ptr)
+                    assert np.array_equal(kept, np.where(n >= 3, n - np.maximum(1, (n * .2).astype(int)), n))
+                    assert (np.diff(v.rows) > 0).all()                       # kept nodes stay sorted
+                    want = OG.subgraph(torch.from_numpy(v.rows), b.edge_index, b.num_nodes).numpy()
+                    if v.edges.shape[1] == want.shape[1]:
+                        assert np.array_equal(v.edges, want)                  # == PyG subgraph(relabel_nodes=True)
+                    else:                                                     # some graph drew an edge drop
+                        saw_edge_drop = True
+                        assert v.edges.shape[1] < want.shape[1]
+                        assert set(map(tuple, v.edges.T)) <= set(map(tuple, want.T))
+                    if v.rowmask is not None:
+                        saw_attr_mask = True
+                        m = max(1, int(b.x.size(1) * .2))
+                        pop = np.array([bin(int(w)).count("1") for w in v.rowmask])
+                        assert set(pop.tolist()) <= {0, m}
+                both = np.intersect1d(v1.rows, v2.rows)
+                assert np.array_equal(v1.rows[v1.common], both) and np.array_equal(v2.rows[v2.common], both)
+    assert saw_edge_drop and saw_attr_mask
+
+
+def test_plan_layout_is_task_major_and_consistent():
+    gen = torch.Generator().manual_seed(6)
+    host = S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"])
+    for mode in ("reference", "vectorized"):
+        e, inp = _planner(mode), _Inp(host)
+        p = e.plan(inp, e.draw(inp, gen))
+        assert p.S == 28 and p.seg_task == sorted(p.seg_task) and p.task_row[-1] == p.N
+        assert p.a64["edge_index"].min() >= 0 and p.a64["edge_index"].max() < p.N
+        seg_of_row = np.searchsorted(np.asarray(p.seg_ptr), np.arange(p.N), side="right") - 1
+        ei = p.a64["edge_index"]
+        assert np.array_equal(seg_of_row[ei[0]], seg_of_row[ei[1]])           # block diagonal: no edge crosses a segment
+        assert p.a32["tiles"].shape == (p.num_tiles, 2)
+        assert (p.a64["nfm_idx"] < p.task_row[1]).all() and (p.a64["nc_idx"] >= p.task_row[2]).all()
