@@ -9,6 +9,7 @@
 // floats per half-wave: conflict-free ds_read_b32.  Global tiles are prefetched into
 // registers one K-step ahead of the MFMAs.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gnnmp_internal.h"
 
@@ -110,7 +111,7 @@ struct GemmArgs {
 };
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
     using LA = TileLoader<BM, A_KMAJOR>;
     using LB = TileLoader<BN, B_KMAJOR>;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     int64_t m0 = (int64_t)blockIdx.y * BM;
     const int64_t n0 = (int64_t)blockIdx.x * BN;
 
+    // NB: `g` lives in the kernarg segment; it is never written (a write would force a private copy of the
+    // whole 700-byte struct into scratch and turn every field access into a scratch load)
+    const float* __restrict__ Bp = g.B;
+    const float* __restrict__ biasp = g.bias;
+    float* Cp = g.C;
+    int64_t Mrows = g.M;
     // k range of this block (split-K slices are multiples of BK)
     int64_t kbeg = 0, kend = g.K;
     if (g.groups > 0) {
@@ -129,13 +136,13 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
         if (A_KMAJOR && B_KMAJOR) {            // TN: reduction range = the group's rows
             kbeg = g.grow[grp];
             kend = g.grow[grp + 1];
-            g.C += g.coff[grp];
+            Cp += g.coff[grp];
         } else {                                // NT / NN: row range of A and C, per-group B (and bias)
             m0 += g.grow[grp];
-            g.M = g.grow[grp + 1];
-            if (m0 >= g.M) return;
-            g.B += g.boff[grp];
-            if (g.bias) g.bias += g.biasoff[grp];
+            Mrows = g.grow[grp + 1];
+            if (m0 >= Mrows) return;
+            Bp += g.boff[grp];
+            if (biasp) biasp += g.biasoff[grp];
         }
     } else if (g.splitk > 1) {
         const int64_t steps = (g.K + BK - 1) / BK;
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     LA la;
     LB lb;
     if (kbeg < kend) {
-        la.load(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, t);
-        lb.load(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, t);
+        la.load(g.A, g.lda, m0, Mrows, kbeg, kend, g.vecA, t);
+        lb.load(Bp, g.ldb, n0, g.N, kbeg, kend, g.vecB, t);
     }
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         la.store(As, t);
@@ -169,8 +176,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
             for (int kk = 0; kk < BK; ++kk) colacc += As[kk * LA::LD + t];
         }
         if (k0 + BK < kend) {   // prefetch the next K-step while this one is multiplied
-            la.load(g.A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, t);
-            lb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t);
+            la.load(g.A, g.lda, m0, Mrows, k0 + BK, kend, g.vecA, t);
+            lb.load(Bp, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -188,12 +195,12 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    if (want_asum && t < BM && m0 + t < g.M) g.asum[g.asumoff[blockIdx.z] + m0 + t] = colacc;
+    if (want_asum && t < BM && m0 + t < Mrows) g.asum[g.asumoff[blockIdx.z] + m0 + t] = colacc;
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* out = g.C;
+    float* out = Cp;
     int64_t ldo = g.ldc;
-    const bool partial = g.splitk > 1;
+    const bool partial = g.splitk > 1 && g.groups == 0;
     if (partial) {
         out = g.partial + (int64_t)blockIdx.z * g.M * g.N;
         ldo = g.N;
@@ -204,11 +211,11 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) {
             const int64_t col = n0 + wn * (BN / 2) + j * 32 + l31;
             if (col >= g.N) continue;
-            const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+            const float bv = (!partial && biasp) ? biasp[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
+                if (row >= Mrows) continue;
                 float v = acc[i][j][r];
                 if (!partial) {
                     v = g.alpha * v + bv;
@@ -304,12 +311,17 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
         g.splitk = (int)(want / ((size_t)M * N * sizeof(float)));
         g.partial = (float*)workspace;
     }
-    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (g.splitk == 1 && big_tiles >= 256) {
-        launch_mode<128, 128>(mode, g, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), 1), st);
-    } else {
-        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st);
-    }
+    // tile choice: the largest tile that still gives every CU work (bigger tiles hide the global-load latency of a
+    // K-step behind 2-4x more MFMA work); GMP_GEMM_TILE=0/1/2 forces 64x64 / 128x64 / 128x128 (tuning aid)
+    static const int forced = getenv("GMP_GEMM_TILE") ? atoi(getenv("GMP_GEMM_TILE")) : -1;
+    const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t12864 = ((M + 127) / 128) * ((N + 63) / 64);
+    int tile = 0;
+    (void)t12864;
+    if (g.splitk == 1) tile = t128 >= 4096 ? 2 : 0;     // measured on MI355X: 64x64 wins until the grid is many waves deep
+    if (forced >= 0 && g.splitk == 1) tile = forced;
+    if (tile == 2) launch_mode<128, 128>(mode, g, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), 1), st);
+    else if (tile == 1) launch_mode<128, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128), 1), st);
+    else launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st);
     if (int rc = gmp::check_launch("gemm_kernel")) return rc;
     if (g.splitk > 1) {
         int blocks = (int)std::min<int64_t>((M * N + 255) / 256, 2048);

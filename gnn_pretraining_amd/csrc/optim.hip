@@ -48,30 +48,41 @@ struct MtArgs {
     float beta1, beta2, eps, max_norm;
 };
 
-__global__ __launch_bounds__(TB) void gram_kernel(MtArgs a) {
+__global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
     const int k = blockIdx.x, j = blockIdx.y;
-    int holders[MAXT], nh = 0;
-    for (int t = 0; t < a.T; ++t)
-        if (a.has[k * MAXT + t]) holders[nh++] = t;
+    bool has[MAXT];
+    int nh = 0;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        has[t] = t < a.T && a.has[k * MAXT + t];
+        nh += has[t];
+    }
     if (nh < 2) return;                         // nothing to project against
-    const int npair = nh * (nh + 1) / 2;
     const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
     const int lo = j * per, hi = min(lo + per, len);
     double* out = a.gram_part + ((int64_t)k * GCH + j) * (MAXT * MAXT);
+    // all MAXT x MAXT upper-triangle products with compile-time indices (runtime-indexed arrays would live in scratch)
     float acc[MAXT * (MAXT + 1) / 2];
-    for (int p = 0; p < npair; ++p) acc[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < MAXT * (MAXT + 1) / 2; ++p) acc[p] = 0.f;
     const int64_t off = a.off[k];
     for (int i = lo + threadIdx.x; i < hi; i += TB) {     // <= 16 elements per thread: fp32 partials are exact enough
         float g[MAXT];
-        for (int h = 0; h < nh; ++h) g[h] = a.tg[(int64_t)holders[h] * a.stride + off + i];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) g[t] = has[t] ? a.tg[(int64_t)t * a.stride + off + i] : 0.f;
         int p = 0;
-        for (int x = 0; x < nh; ++x)
-            for (int y = x; y < nh; ++y) acc[p++] += g[x] * g[y];
+#pragma unroll
+        for (int x = 0; x < MAXT; ++x)
+#pragma unroll
+            for (int y = x; y < MAXT; ++y) acc[p++] += g[x] * g[y];
     }
     __shared__ double sh[TB];
     int p = 0;
-    for (int x = 0; x < nh; ++x)
-        for (int y = x; y < nh; ++y, ++p) {
+#pragma unroll
+    for (int x = 0; x < MAXT; ++x)
+#pragma unroll
+        for (int y = x; y < MAXT; ++y, ++p) {
+            if (!(has[x] && has[y])) continue;            // block-uniform
             __syncthreads();
             sh[threadIdx.x] = (double)acc[p];
             __syncthreads();
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(TB) void gram_kernel(MtArgs a) {
                 if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
                 __syncthreads();
             }
-            if (threadIdx.x == 0) out[holders[x] * MAXT + holders[y]] = sh[0];
+            if (threadIdx.x == 0) out[x * MAXT + y] = sh[0];
         }
 }
 
