@@ -65,7 +65,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_segment_max_bwd": (C.c_int, [p, p, p, p, p, i64, i32, i32, p]),
     "gmp_gemm_f32_workspace_bytes": (sz, [i32, i64, i64, i64]),
     "gmp_gemm_f32": (C.c_int, [i32, p, p, p, p, i64, i64, i64, i64, i64, i64, f32, i32, i32, p, sz, p]),
-    "gmp_gemm_f32_grouped": (C.c_int, [i32, p, p, p, p, i32, p, p, p, p, p, p, i64, i64, i64, i64, i64, i64, f32, i32, i32, p]),
+    "gmp_gemm_f32_grouped": (C.c_int, [i32, p, p, p, p, i32, p, p, p, p, p, p, i64, i64, i64, i64, i64, i64, f32, i32, i32, p, sz, p]),
     "gmp_gin_aggregate_bwd_ex": (C.c_int, [p, p, p, p, p, p, p, p, i64, i32, p]),
     "gmp_group_sum_1d": (C.c_int, [p, i32, p, p, p, p]),
     "gmp_colsum_workspace_bytes": (sz, [i64, i64]),
@@ -92,7 +92,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_cross_entropy_sum_bwd": (C.c_int, [p, p, i64, i32, p, p, p]),
     "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),
     "gmp_encoder_fwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, p, p, p, i32, p, p]),
-    "gmp_encoder_bwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, i32, p, p, p, p, p]),
+    "gmp_encoder_bwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, i32, p, p, p, p, p, sz, p]),
     "gmp_mt_workspace_bytes": (sz, [i32]),
     "gmp_mt_pcgrad_clip_adamw": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
                                            f32, p, p, p, p, p, sz, i32, p]),

@@ -168,6 +168,20 @@ __global__ __launch_bounds__(THREADS) void bn_running_kernel(BnArgs a) {
     const int c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.C) return;
     const float m = a.cfg.momentum;
+    if (!a.seg_group) {                  // one parameter set: keep the running pair in registers, loads stay independent
+        float rm = a.running_mean[c], rv = a.running_var[c];
+        for (int s = 0; s < a.S; ++s) {
+            const int n = a.seg_ptr[s + 1] - a.seg_ptr[s];
+            if (n <= 0) continue;
+            const float mean = a.save_mean[(int64_t)s * a.C + c], rstd = a.save_rstd[(int64_t)s * a.C + c];
+            const float var = 1.f / (rstd * rstd) - a.cfg.eps;
+            rm = (1.f - m) * rm + m * mean;
+            rv = (1.f - m) * rv + m * (n > 1 ? var * ((float)n / (float)(n - 1)) : var);
+        }
+        a.running_mean[c] = rm;
+        a.running_var[c] = rv;
+        return;
+    }
     for (int s = 0; s < a.S; ++s) {      // one thread owns column c of every group: sequential, race-free
         const int n = a.seg_ptr[s + 1] - a.seg_ptr[s];
         if (n <= 0) continue;

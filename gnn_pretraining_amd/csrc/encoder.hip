@@ -76,13 +76,18 @@ struct EncBwdArgs {
     int gseg[GMP_MAX_GROUPS + 1];
     int64_t off_w[GMP_MAX_GROUPS], off_b[GMP_MAX_GROUPS];
     float* out;                 // per-task gradient buffer
+    float* part;                // nullable: [groups][RSPLIT][256][DP+1] row-slice partials
 };
+constexpr int RSPLIT = 8;
 
-// one block per group: dW[c][k] = sum_r gz[r][c] x[r][k], db[c] = sum_r gz[r][c]; rows walked in order (deterministic)
+// block (group, slice): dW[c][k] = sum_r gz[r][c] x[r][k], db[c] = sum_r gz[r][c] over every RSPLIT-th 32-row tile of the
+// group (all of them without a workspace); partials are summed in slice order by encoder_bwd_reduce_kernel
 template <int DP>
-__global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
+__global__ __launch_bounds__(H) void encoder_bwd_kernel(const EncBwdArgs a) {
     __shared__ float xs[TR][DP + 1];
     const int g = blockIdx.x, c = threadIdx.x;
+    const int nsl = a.part ? RSPLIT : 1, sl = blockIdx.y;
+    int tile = 0;
     float acc[DP], accb = 0.f;
 #pragma unroll
     for (int k = 0; k < DP; ++k) acc[k] = 0.f;
@@ -91,7 +96,8 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
         const int dom = a.seg_dom[seg];
         din = a.d_in[dom];
         const int s1 = min(a.seg_ptr[seg + 1], a.num_rows);
-        for (int r0 = max(a.seg_ptr[seg], 0); r0 < s1; r0 += TR) {
+        for (int r0 = max(a.seg_ptr[seg], 0); r0 < s1; r0 += TR, ++tile) {
+            if (tile % nsl != sl) continue;            // block-uniform
             const int r1 = min(r0 + TR, s1);
             __syncthreads();
             for (int i = c; i < TR * DP; i += H) {
@@ -113,13 +119,38 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(EncBwdArgs a) {
             }
         }
     }
-    if (a.gseg[g + 1] > a.gseg[g]) {
+    if (a.part) {
+        float* po = a.part + (((int64_t)g * RSPLIT + sl) * H + c) * (DP + 1);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) po[k] = acc[k];
+        po[DP] = accb;
+    } else if (a.gseg[g + 1] > a.gseg[g]) {
         float* wo = a.out + a.off_w[g] + (int64_t)c * din;
 #pragma unroll
         for (int k = 0; k < DP; ++k)
             if (k < din) wo[k] = acc[k];
         a.out[a.off_b[g] + c] = accb;
     }
+}
+
+template <int DP>
+__global__ __launch_bounds__(H) void encoder_bwd_reduce_kernel(const EncBwdArgs a) {
+    const int g = blockIdx.x, c = threadIdx.x;
+    if (a.gseg[g + 1] <= a.gseg[g]) return;
+    const int din = a.d_in[a.seg_dom[a.gseg[g]]];
+    float acc[DP + 1];
+#pragma unroll
+    for (int k = 0; k <= DP; ++k) acc[k] = 0.f;
+    for (int sl = 0; sl < RSPLIT; ++sl) {
+        const float* po = a.part + (((int64_t)g * RSPLIT + sl) * H + c) * (DP + 1);
+#pragma unroll
+        for (int k = 0; k <= DP; ++k) acc[k] += po[k];
+    }
+    float* wo = a.out + a.off_w[g] + (int64_t)c * din;
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+        if (k < din) wo[k] = acc[k];
+    a.out[a.off_b[g] + c] = acc[DP];
 }
 
 }  // namespace
@@ -152,7 +183,8 @@ extern "C" int gmp_encoder_fwd(const float* x_all, int64_t num_x_rows, int64_t n
 extern "C" int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                                const uint64_t* row_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
                                int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
-                               const int64_t* off_b_host, float* grad_out, gmp_stream_t stream) {
+                               const int64_t* off_b_host, float* grad_out, void* workspace, size_t workspace_bytes,
+                               gmp_stream_t stream) {
     if (groups < 0 || groups > GMP_MAX_GROUPS || num_domains < 1 || num_domains > MAXD || dpad < 1 || dpad > DPAD_MAX)
         return gmp::fail(GMP_ERR_ARG, "encoder_bwd: groups=%d domains=%d dpad=%d", groups, num_domains, dpad);
     if (groups == 0) return GMP_OK;
@@ -166,9 +198,19 @@ extern "C" int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t n
     for (int g = 0; g <= groups; ++g) a.gseg[g] = group_seg_host[g];
     for (int g = 0; g < groups; ++g) { a.off_w[g] = off_w_host[g]; a.off_b[g] = off_b_host[g]; }
     hipStream_t st = (hipStream_t)stream;
-    if (dpad <= 8) hipLaunchKernelGGL(encoder_bwd_kernel<8>, dim3(groups), dim3(H), 0, st, a);
-    else if (dpad <= 24) hipLaunchKernelGGL(encoder_bwd_kernel<24>, dim3(groups), dim3(H), 0, st, a);
-    else if (dpad <= 40) hipLaunchKernelGGL(encoder_bwd_kernel<40>, dim3(groups), dim3(H), 0, st, a);
-    else hipLaunchKernelGGL(encoder_bwd_kernel<64>, dim3(groups), dim3(H), 0, st, a);
+    const int dp = dpad <= 8 ? 8 : (dpad <= 24 ? 24 : (dpad <= 40 ? 40 : 64));
+    const size_t need = (size_t)groups * RSPLIT * H * (dp + 1) * sizeof(float);
+    a.part = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
+    const dim3 grid(groups, a.part ? RSPLIT : 1);
+#define GMP_ENC_BWD(DPV)                                                                  \
+    do {                                                                                  \
+        hipLaunchKernelGGL(encoder_bwd_kernel<DPV>, grid, dim3(H), 0, st, a);             \
+        if (a.part) hipLaunchKernelGGL(encoder_bwd_reduce_kernel<DPV>, dim3(groups), dim3(H), 0, st, a); \
+    } while (0)
+    if (dp == 8) GMP_ENC_BWD(8);
+    else if (dp == 24) GMP_ENC_BWD(24);
+    else if (dp == 40) GMP_ENC_BWD(40);
+    else GMP_ENC_BWD(64);
+#undef GMP_ENC_BWD
     return gmp::check_launch("encoder_bwd_kernel");
 }

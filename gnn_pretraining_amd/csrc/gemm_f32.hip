@@ -108,6 +108,11 @@ struct GemmArgs {
     // g^T 1 rides along with the weight gradient g^T x: the A tile is already in LDS)
     float* asum;
     int64_t asumoff[MAXG];
+    // grouped TN split over row slices: blockIdx.z = group * gsplit + slice; partial tiles -> gpart[z][M][N] and
+    // partial column sums -> gasum_part[z][M], summed in slice order by grouped_reduce_kernel (deterministic)
+    int gsplit;
+    float* gpart;
+    float* gasum_part;
 };
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
@@ -132,11 +137,18 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
     // k range of this block (split-K slices are multiples of BK)
     int64_t kbeg = 0, kend = g.K;
     if (g.groups > 0) {
-        const int grp = blockIdx.z;
-        if (A_KMAJOR && B_KMAJOR) {            // TN: reduction range = the group's rows
+        const int grp = (A_KMAJOR && B_KMAJOR) ? blockIdx.z / g.gsplit : blockIdx.z;
+        if (A_KMAJOR && B_KMAJOR) {            // TN: reduction range = the group's rows (or one slice of them)
             kbeg = g.grow[grp];
             kend = g.grow[grp + 1];
-            Cp += g.coff[grp];
+            if (g.gsplit > 1) {
+                const int64_t steps = (kend - kbeg + BK - 1) / BK, per = (steps + g.gsplit - 1) / g.gsplit;
+                kbeg += (int64_t)(blockIdx.z % g.gsplit) * per * BK;
+                kend = kbeg + per * BK < kend ? kbeg + per * BK : kend;
+                Cp = g.gpart + (int64_t)blockIdx.z * g.M * g.N;
+            } else {
+                Cp += g.coff[grp];
+            }
         } else {                                // NT / NN: row range of A and C, per-group B (and bias)
             m0 += g.grow[grp];
             Mrows = g.grow[grp + 1];
@@ -195,16 +207,18 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
-    if (want_asum && t < BM && m0 + t < Mrows) g.asum[g.asumoff[blockIdx.z] + m0 + t] = colacc;
+    if (want_asum && t < BM && m0 + t < Mrows) {
+        if (g.gsplit > 1) g.gasum_part[(int64_t)blockIdx.z * g.M + m0 + t] = colacc;
+        else g.asum[g.asumoff[blockIdx.z] + m0 + t] = colacc;
+    }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* out = Cp;
     int64_t ldo = g.ldc;
-    const bool partial = g.splitk > 1 && g.groups == 0;
-    if (partial) {
-        out = g.partial + (int64_t)blockIdx.z * g.M * g.N;
-        ldo = g.N;
-    }
+    const bool gpartial = A_KMAJOR && B_KMAJOR && g.groups > 0 && g.gsplit > 1;
+    const bool partial = (g.splitk > 1 && g.groups == 0) || gpartial;
+    if (g.splitk > 1 && g.groups == 0) out = g.partial + (int64_t)blockIdx.z * g.M * g.N;
+    if (partial) ldo = g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -238,6 +252,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
         if (g.accumulate) v += g.C[row * g.ldc + col];
         if (g.relu) v = fmaxf(v, 0.f);
         g.C[row * g.ldc + col] = v;
+    }
+}
+
+// grouped TN split: C_g = alpha * sum_slices partial, column sums likewise (slice order: deterministic)
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(const GemmArgs g) {
+    const int grp = blockIdx.y;
+    const int64_t total = g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total + g.M; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        if (i < total) {
+            for (int z = 0; z < g.gsplit; ++z) s += g.gpart[((int64_t)grp * g.gsplit + z) * total + i];
+            g.C[g.coff[grp] + (i / g.N) * g.ldc + i % g.N] = g.alpha * s;
+        } else if (g.asum) {
+            const int64_t m = i - total;
+            for (int z = 0; z < g.gsplit; ++z) s += g.gasum_part[((int64_t)grp * g.gsplit + z) * g.M + m];
+            g.asum[g.asumoff[grp] + m] = s;
+        }
     }
 }
 
@@ -335,8 +366,8 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
                                     const int32_t* group_rows_host, const int64_t* b_off_host,
                                     const int64_t* bias_off_host, const int64_t* c_off_host, float* a_colsum,
                                     const int64_t* a_colsum_off_host, int64_t M_tn, int64_t N, int64_t K, int64_t lda,
-                                    int64_t ldb, int64_t ldc, float alpha, int accumulate, int relu,
-                                    gmp_stream_t stream) {
+                                    int64_t ldb, int64_t ldc, float alpha, int accumulate, int relu, void* workspace,
+                                    size_t workspace_bytes, gmp_stream_t stream) {
     if (mode < 0 || mode > 2) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: mode %d", mode);
     if (groups < 1 || groups > MAXG || !group_rows_host) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: %d groups (max %d)", groups, MAXG);
     if (N <= 0 || K < 0 || !A || !B || !C) return gmp::fail(GMP_ERR_ARG, "gemm_grouped: bad argument");
@@ -346,6 +377,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     g.vecA = (lda % 4 == 0) && aligned16(A);
     g.vecB = (ldb % 4 == 0) && aligned16(B);
     g.groups = groups;
+    g.gsplit = 1;
     g.asum = mode == GMP_GEMM_TN ? a_colsum : nullptr;
     int64_t max_rows = 0;
     for (int i = 0; i <= groups; ++i) {
@@ -365,7 +397,25 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         g.M = M_tn;          // output rows = columns of A (k-major A: lda >= M_tn); the reduction runs over the group's rows
         g.K = 0;
         if (g.M == 0) return GMP_OK;
-        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)groups), st);
+        // few output tiles x long reductions: slice every group's rows over several blocks when a workspace is given
+        const int64_t tiles = ((N + 63) / 64) * ((g.M + 63) / 64) * groups;
+        int split = 1;
+        if (workspace && tiles < 384 && max_rows >= 8 * BK) {
+            split = (int)std::min<int64_t>((512 + tiles - 1) / tiles, max_rows / (4 * BK));
+            const size_t need = (size_t)groups * split * (g.M * N + g.M) * sizeof(float);
+            if (split < 2 || need > workspace_bytes) split = 1;
+        }
+        g.gsplit = split;
+        if (split > 1) {
+            g.gpart = (float*)workspace;
+            g.gasum_part = g.gpart + (size_t)groups * split * g.M * N;
+        }
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(groups * split)), st);
+        if (split > 1) {
+            if (int rc = gmp::check_launch("gemm_kernel (grouped, split)")) return rc;
+            int blocks = (int)std::min<int64_t>((g.M * N + g.M + 255) / 256, 256);
+            hipLaunchKernelGGL(grouped_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, g);
+        }
     } else {
         if (max_rows == 0) return GMP_OK;
         g.M = 0;

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int MAXT = 8;        // tasks
-constexpr int CH = 8;          // chunks per tensor in the elementwise kernels
+constexpr int CH = 32;         // chunks per tensor in the elementwise kernels (the 131k-element weights dominate)
 constexpr int GCH = 32;        // chunks per tensor in the Gram pass (the 131k-element weights need many blocks)
 constexpr int TB = 256;
 

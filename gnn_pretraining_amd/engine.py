@@ -207,6 +207,7 @@ class StepEngine:
         self.gW = f(R, 2 * H)                                # [R,512] gradients
         self.gW2 = f(R, 2 * H)
         self.rowdot = f(R)
+        self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(R, 2 * H, self.S_MAX, 512), dtype=torch.uint8, device=dev)
         self.csr_ws = torch.empty(self.lib.gmp_csr_build_workspace_bytes(R, self.max_edges), dtype=torch.uint8, device=dev)
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
@@ -529,7 +530,8 @@ class StepEngine:
         self._chk(self.lib.gmp_gemm_f32_grouped(mode, A, B, bias, Cc, G, _i32(rows), None if boff is None else _i64(boff),
                                                 None if biasoff is None else _i64(biasoff), None if coff is None else _i64(coff),
                                                 asum, None if asumoff is None else _i64(asumoff), M_tn, N, K, lda, ldb, ldc, 1.0, 0,
-                                                int(relu), self._st()), "gemm_grouped")
+                                                int(relu), self.gemm_ws.data_ptr() if mode == TN else None, self.gemm_ws.numel(),
+                                                self._st()), "gemm_grouped")
 
     def _bn_cfg(self, relu: bool, dropout: bool, site: int) -> L.BnConfig:
         p = self.dropout_p if (dropout and self.model.training) else 0.0
@@ -885,7 +887,8 @@ class StepEngine:
         self._chk(lib.gmp_encoder_bwd(inp.x_all.data_ptr(), inp.x_all.size(0), N, p.S, p.d32["src_row"], p.d32["seg_ptr"], p.d32["seg_dom"], p.d64.get("rowmask"),
                                       gu.data_ptr(), len(D), _i32(d_in), self.dpad, len(groups), _i32(ptr),
                                       _i64([TG(ti, f"input_encoders.{d}.linear.weight") for (ti, d, _, _) in groups]),
-                                      _i64([TG(ti, f"input_encoders.{d}.linear.bias") for (ti, d, _, _) in groups]), tg, st), "encoder bwd")
+                                      _i64([TG(ti, f"input_encoders.{d}.linear.bias") for (ti, d, _, _) in groups]), tg,
+                                      self.gemm_ws.data_ptr(), self.gemm_ws.numel(), st), "encoder bwd")
 
     # ---- optimizer ---------------------------------------------------------------------------------
     def _optimizer(self, p: StepPlan, order: Optional[List[str]], apply_update: bool) -> None:

@@ -140,12 +140,14 @@ int gmp_gemm_f32(int mode, const float* A, const float* B, const float* bias, fl
  *            offsets point into the per-task gradient buffer PCGrad reads).
  *            a_colsum (nullable): a_colsum + a_colsum_off_host[g] + m receives sum over the group's rows of
  *            A[:, m] -- the bias gradient rides along with the weight gradient for free.
+ *            workspace (nullable): lets TN slice each group's rows over several workgroups (partials summed
+ *            in slice order by a second kernel) when the output alone cannot fill the chip.
  * Offsets are in floats; NULL offset arrays mean 0. */
 int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, const float* bias, float* C, int groups,
                          const int32_t* group_rows_host, const int64_t* b_off_host, const int64_t* bias_off_host,
                          const int64_t* c_off_host, float* a_colsum, const int64_t* a_colsum_off_host,
                          int64_t M_tn, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha,
-                         int accumulate, int relu, gmp_stream_t stream);
+                         int accumulate, int relu, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 /* column sums: out[n] (+)= sum_m A[m,n]  (bias gradient), rows [0,M) */
 size_t gmp_colsum_workspace_bytes(int64_t M, int64_t N);
 int gmp_colsum(const float* A, float* out, int64_t M, int64_t N, int64_t lda, int accumulate,
@@ -282,7 +284,8 @@ int gmp_encoder_fwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, in
 int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, int num_segments, const int32_t* src_row, const int32_t* seg_ptr, const int32_t* seg_dom,
                     const uint64_t* row_colmask, const float* g_z, int num_domains, const int32_t* d_in_host,
                     int dpad, int groups, const int32_t* group_seg_host, const int64_t* off_w_host,
-                    const int64_t* off_b_host, float* grad_out, gmp_stream_t stream);
+                    const int64_t* off_b_host, float* grad_out, void* workspace, size_t workspace_bytes,
+                    gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Multi-tensor PCGrad + clip_grad_norm_ + AdamW over flat buffers (gradient_surgery.py:41-103,
