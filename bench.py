@@ -35,6 +35,11 @@ from gnn_pretraining_amd.pretrain.control import TemperatureScheduler  # noqa: E
 SCHEME = "s4"
 GRAPHS_PER_STEP = 32
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+# HBM bytes per launch of the aggregation kernel at exactly this rung, from separate rocprofv3 --pmc passes
+# (profiles/r01_pmc_aggregate_stream.csv): FETCH_SIZE 1,352,746 KB x 2 (gfx950 reports half of wide coalesced reads,
+# MI355X_MICROARCH.md section HBM) + WRITE_SIZE 2,146,816 KB, x 1024.  PMC passes cannot run inside this process.
+PMC_SHAPE = (2146816, 8068480)
+PMC_TRAFFIC_BYTES = int((1352745.6 * 2 + 2146816.0) * 1024)
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
 
 
@@ -103,7 +108,7 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     alg_bytes = 2 * 4 * 256 * N + 4 * (N + 1) + 4 * E
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "gin_aggregate_stream_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES if (N, E) == PMC_SHAPE else None, "kernel": "gin_aggregate_stream_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters}
 
 
@@ -144,19 +149,25 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
     ap.add_argument("--rng", choices=["reference", "vectorized"], default="vectorized",
                     help="how the step's augmentation/mask/negative indices are drawn on the host: 'reference' = the exact "
                          "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
                          "distributions, all graphs of a domain at once (numpy)")
     a = ap.parse_args()
 
-    world = D.init_from_env()
+    if a.roofline_only:
+        torch.cuda.set_device(0)
+        print(json.dumps({"roofline": aggregation_roofline(torch.device("cuda:0"))}))
+        return
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    device = torch.device(f"cuda:{local % ndev}")       # one rank per GPU; (rehearsals on a 1-GPU box share it over gloo)
+    torch.cuda.set_device(device)
+    world = D.init_from_env(os.environ.get("GMP_DIST_BACKEND"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     rank = D.rank()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(device)
 
     seed = 42
     torch.manual_seed(seed)                        # identical replicas on every rank

@@ -10,6 +10,8 @@
 // graph (which sit next to each other in the batch) are re-read from that XCD's
 // own L2 instead of crossing to HBM again.  HBM-bound: compulsory traffic is
 // read x once + write out once.
+#include <cstdlib>
+
 #include "gnnmp_internal.h"
 
 namespace {
@@ -119,11 +121,13 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
 // row of x leaves HBM once; rowptr and col of a tile are staged into LDS with two coalesced block-wide
 // loads, leaving ONE memory latency per row; the output is written with non-temporal stores so it does not
 // evict the x rows waiting to be re-read.
-constexpr int SB = 1024, SWAVES = SB / GMP_WAVE, TILE = 256, COLCAP = 3072;
+constexpr int COLCAP = 3072;
 
+template <int SB, int TILE, bool NT_STORE>
 __global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
                                                                   const int* __restrict__ col, const float* __restrict__ eps,
                                                                   float4* __restrict__ out, int64_t nrows, int tiles_per_block) {
+    constexpr int SWAVES = SB / GMP_WAVE;
     __shared__ int s_ptr[TILE + 1];
     __shared__ int s_col[COLCAP];
     const int per_xcd = gridDim.x / NUM_XCD;
@@ -163,11 +167,15 @@ __global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* 
                 const int64_t u = __builtin_amdgcn_readfirstlane(cc);
                 acc = f4add(acc, x[u * 64 + lane]);
             }
-            float* o = reinterpret_cast<float*>(out + r * 64 + lane);
-            __builtin_nontemporal_store(acc.x, o);
-            __builtin_nontemporal_store(acc.y, o + 1);
-            __builtin_nontemporal_store(acc.z, o + 2);
-            __builtin_nontemporal_store(acc.w, o + 3);
+            if (NT_STORE) {
+                float* o = reinterpret_cast<float*>(out + r * 64 + lane);
+                __builtin_nontemporal_store(acc.x, o);
+                __builtin_nontemporal_store(acc.y, o + 1);
+                __builtin_nontemporal_store(acc.z, o + 2);
+                __builtin_nontemporal_store(acc.w, o + 3);
+            } else {
+                out[r * 64 + lane] = acc;
+            }
         }
     }
 }
@@ -251,11 +259,27 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
     if (feat == 256 && N >= 65536) {          // working set beyond the caches: streaming kernel
-        const int64_t ntiles = (N + TILE - 1) / TILE;
-        int blocks = 512;                       // 2 resident 1024-thread workgroups per CU
-        int tpb = (int)((ntiles + blocks - 1) / blocks);
-        hipLaunchKernelGGL(gin_aggregate_stream_kernel, dim3(blocks), dim3(SB), 0, (hipStream_t)stream, (const float4*)x, rowptr, col,
-                           eps, (float4*)out, N, tpb);
+        // GMP_AGG_VARIANT (tuning aid): 0 = 1024 threads / 256-row tiles / nt stores, 1 = same with plain stores,
+        // 2 = 512-row tiles, 3 = 512 threads / 128-row tiles (default), 4 = 512 threads / 256-row tiles; GMP_AGG_BLOCKS = grid
+        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 3;
+        static const int blocks_env = getenv("GMP_AGG_BLOCKS") ? atoi(getenv("GMP_AGG_BLOCKS")) : 0;
+        hipStream_t st = (hipStream_t)stream;
+#define GMP_STREAM(SBV, TILEV, NTV, DEFBLOCKS)                                                                        \
+        do {                                                                                                          \
+            const int64_t ntiles = (N + TILEV - 1) / TILEV;                                                           \
+            int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \
+            int tpb = (int)((ntiles + blocks - 1) / blocks);                                                          \
+            hipLaunchKernelGGL((gin_aggregate_stream_kernel<SBV, TILEV, NTV>), dim3(blocks), dim3(SBV), 0, st,        \
+                               (const float4*)x, rowptr, col, eps, (float4*)out, N, tpb);                            \
+        } while (0)
+        switch (variant) {
+            case 1: GMP_STREAM(1024, 256, false, 512); break;
+            case 2: GMP_STREAM(1024, 512, true, 512); break;
+            case 0: GMP_STREAM(1024, 256, true, 512); break;
+            case 4: GMP_STREAM(512, 256, true, 1024); break;
+            default: GMP_STREAM(512, 128, true, 1024); break;   // best median of the sweep in profiles/README.md
+        }
+#undef GMP_STREAM
         return gmp::check_launch("gin_aggregate_stream_kernel");
     }
     Plan p = make_plan(N);
