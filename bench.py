@@ -197,7 +197,9 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    hm = engine.host_ms
     log(f"{a.steps} steps in {elapsed:.3f} s; last-step losses {engine.losses()}")
+    log("host ms/step: " + ", ".join(f"{k} {hm[k] / max(hm['steps'], 1):.2f}" for k in ("draw", "plan", "upload", "launch")))
     roof = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)

@@ -43,12 +43,28 @@ MAXT = 8
 SUPPORTED_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop")
 
 
+_ARR_CACHE: Dict[Tuple, "C.Array"] = {}
+
+
 def _i32(xs) -> "C.Array":
-    return (C.c_int32 * len(xs))(*[int(v) for v in xs])
+    """ctypes int32 array; memoised by content (offset/row tables repeat every step)."""
+    key = (32,) + tuple(xs)
+    a = _ARR_CACHE.get(key)
+    if a is None:
+        if len(_ARR_CACHE) > 20000:
+            _ARR_CACHE.clear()
+        a = _ARR_CACHE[key] = (C.c_int32 * len(xs))(*[int(v) for v in xs])
+    return a
 
 
 def _i64(xs) -> "C.Array":
-    return (C.c_int64 * len(xs))(*[int(v) for v in xs])
+    key = (64,) + tuple(xs)
+    a = _ARR_CACHE.get(key)
+    if a is None:
+        if len(_ARR_CACHE) > 20000:
+            _ARR_CACHE.clear()
+        a = _ARR_CACHE[key] = (C.c_int64 * len(xs))(*[int(v) for v in xs])
+    return a
 
 
 class StepInputs:
@@ -107,6 +123,9 @@ class StepEngine:
         self.shuffle_rng = shuffle_rng
         self.grad_sync = grad_sync
         self.temperature = 0.5
+        self._p_cache, self._tg_cache = {}, {}
+        self._stream_handle = torch.cuda.current_stream(self.device).cuda_stream if torch.cuda.is_available() else 0
+        self.host_ms = {"draw": 0.0, "plan": 0.0, "upload": 0.0, "launch": 0.0, "steps": 0}   # host time per phase (upload includes ring waits)
         self.dropout_p = DROPOUT_RATE
         self.max_grad_norm = 0.5
         self._flatten_parameters()
@@ -208,11 +227,19 @@ class StepEngine:
         self.gW2 = f(R, 2 * H)
         self.rowdot = f(R)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs
+        # the task heads are independent of each other: each runs on its own stream with its own scratch
+        self.task_streams = [torch.cuda.Stream(device=dev) for _ in range(self.T)]
+        self.aux_stream = torch.cuda.Stream(device=dev)
+        self.task_gemm_ws = [torch.empty(24 << 20, dtype=torch.uint8, device=dev) for _ in range(self.T)]
+        self.task_loss_ws = [torch.empty(self.lib.gmp_loss_workspace_bytes(R * H), dtype=torch.uint8, device=dev) for _ in range(self.T)]
+        self._cur_gemm_ws = self.gemm_ws
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(R, 2 * H, self.S_MAX, 512), dtype=torch.uint8, device=dev)
         self.csr_ws = torch.empty(self.lib.gmp_csr_build_workspace_bytes(R, self.max_edges), dtype=torch.uint8, device=dev)
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
         self.csr = [i32(R + 1), i32(self.max_edges), i32(self.max_edges), i32(R + 1), i32(self.max_edges), i32(self.max_edges)]
         self.csr_status = i32(1)
+        self.lp_csr_status = i32(1)
+        self.lp_csr_ws = torch.empty(self.lib.gmp_csr_build_workspace_bytes(R, self.max_edges), dtype=torch.uint8, device=dev)
         self.lp_csr = [i32(R + 1), i32(self.max_edges), i32(self.max_edges), i32(R + 1), i32(self.max_edges), i32(self.max_edges)]
         self.loss_sums = torch.zeros(MAXT, device=dev)       # per-task loss SUMS of the last step
         self.loss_ws = torch.empty(self.lib.gmp_loss_workspace_bytes(R * H), dtype=torch.uint8, device=dev)
@@ -516,7 +543,11 @@ class StepEngine:
 
     # ------------------------------------------------------------------ device helpers
     def _st(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """hipStream_t the launches go to.  Cached: torch.cuda.current_stream() costs ~5 us and a step makes ~300 launches."""
+        return self._stream_handle
+
+    def _use_stream(self, stream=None) -> None:
+        self._stream_handle = (stream or torch.cuda.current_stream(self.device)).cuda_stream
 
     def _chk(self, rc: int, what: str) -> None:
         if rc:
@@ -530,7 +561,7 @@ class StepEngine:
         self._chk(self.lib.gmp_gemm_f32_grouped(mode, A, B, bias, Cc, G, _i32(rows), None if boff is None else _i64(boff),
                                                 None if biasoff is None else _i64(biasoff), None if coff is None else _i64(coff),
                                                 asum, None if asumoff is None else _i64(asumoff), M_tn, N, K, lda, ldb, ldc, 1.0, 0,
-                                                int(relu), self.gemm_ws.data_ptr() if mode == TN else None, self.gemm_ws.numel(),
+                                                int(relu), self._cur_gemm_ws.data_ptr() if mode == TN else None, self._cur_gemm_ws.numel(),
                                                 self._st()), "gemm_grouped")
 
     def _bn_cfg(self, relu: bool, dropout: bool, site: int) -> L.BnConfig:
@@ -542,13 +573,23 @@ class StepEngine:
              order: Optional[List[str]] = None, apply_update: bool = True) -> None:
         """Forward, backward, PCGrad, clip, AdamW for one step.  Nothing is read back: losses stay in
         self.loss_sums / self.plan_sizes until someone asks (losses())."""
+        import time as _t
+        self._use_stream()
+        t0 = _t.perf_counter()
         if art is None:
             art = self.draw(inp, gen)
+        t1 = _t.perf_counter()
         p = self.plan(inp, art)
+        t2 = _t.perf_counter()
         self._upload(p, inp, art)
+        t3 = _t.perf_counter()
         self._forward(p, inp)
         self._heads_and_backward(p, inp)
         self._optimizer(p, order, apply_update)
+        t4 = _t.perf_counter()
+        h = self.host_ms
+        h["draw"] += (t1 - t0) * 1e3; h["plan"] += (t2 - t1) * 1e3; h["upload"] += (t3 - t2) * 1e3; h["launch"] += (t4 - t3) * 1e3
+        h["steps"] += 1
         self.step_count += 1
         self.last_plan = p
 
@@ -606,18 +647,41 @@ class StepEngine:
 
     # ---- forward -----------------------------------------------------------------------------------
     def _P(self, name: str) -> int:
-        return self.flat.data_ptr() + 4 * self.off[name]
+        v = self._p_cache.get(name)
+        if v is None:
+            v = self._p_cache[name] = self.flat.data_ptr() + 4 * self.off[name]
+        return v
 
     def _TG(self, t: int, name: str) -> int:
         """Float offset of (task t, tensor) inside the [T, P] per-task gradient buffer."""
         return t * self.P + self.off[name]
 
+    def _TGs(self, name: str) -> "C.Array":
+        """Per-task offsets of one tensor (static: cached as a ready ctypes array)."""
+        a = self._tg_cache.get(name)
+        if a is None:
+            a = self._tg_cache[name] = _i64([t * self.P + self.off[name] for t in range(self.T)])
+        return a
+
     def _forward(self, p: StepPlan, inp: StepInputs) -> None:
         lib, st, N, D, P = self.lib, self._st(), p.N, self.domains, self._P
         c = self.csr
-        self._chk(lib.gmp_csr_build(p.d64["edge_index"], N, p.E, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
-                                    c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(),
-                                    self.csr_ws.numel(), st), "csr_build")
+        main = torch.cuda.current_stream(self.device)
+        # both CSR builds depend only on the uploaded indices: they run beside the encoders on the aux stream
+        ev_up = torch.cuda.Event(); ev_up.record(main)
+        self.aux_stream.wait_event(ev_up)
+        with torch.cuda.stream(self.aux_stream):
+            ast = self.aux_stream.cuda_stream
+            self._chk(lib.gmp_csr_build(p.d64["edge_index"], N, p.E, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                                        c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(),
+                                        self.csr_ws.numel(), ast), "csr_build")
+            ev_csr = torch.cuda.Event(); ev_csr.record(self.aux_stream)
+            if "link_pred" in self.tasks:
+                lc = self.lp_csr
+                self._chk(lib.gmp_csr_build(p.d64["lp_edges"], N, p.lp_K, lc[0].data_ptr(), lc[1].data_ptr(), lc[2].data_ptr(), lc[3].data_ptr(),
+                                            lc[4].data_ptr(), lc[5].data_ptr(), self.lp_csr_status.data_ptr(), self.lp_csr_ws.data_ptr(),
+                                            self.lp_csr_ws.numel(), ast), "lp csr")
+            p.ev_lpcsr = torch.cuda.Event(); p.ev_lpcsr.record(self.aux_stream)
         w_off = [self.off[f"input_encoders.{d}.linear.weight"] for d in D]
         b_off = [self.off[f"input_encoders.{d}.linear.bias"] for d in D]
         d_in = [DOMAIN_DIMENSIONS[d] for d in D]
@@ -634,6 +698,7 @@ class StepEngine:
             M = p.nfm_rows[-1]
             self._chk(lib.gmp_row_gather(self.h[0].data_ptr(), p.d64["nfm_idx"], None, self.hd["nfm_tgt"].data_ptr(), M, N, H, st), "nfm target")
             self._chk(lib.gmp_row_fill(self.h[0].data_ptr(), p.d64["nfm_idx"], P("mask_token"), M, N, H, 1, st), "nfm mask")
+        main.wait_event(ev_csr)
         for l in range(GNN_NUM_LAYERS):
             pre = f"gnn_backbone.layers.{l}."
             layer = self.model.gnn_backbone.layers[l]
@@ -710,13 +775,39 @@ class StepEngine:
         gH[:N].zero_()
         sc = self.scal.data_ptr()
         T_ = float(self.temperature)
+        main = torch.cuda.current_stream(self.device)
+        ev_fwd = torch.cuda.Event(); ev_fwd.record(main)
+        done = []
         for ti, t in enumerate(self.tasks):
+            ts = self.task_streams[ti]
+            ts.wait_event(ev_fwd)
+            if t == "link_pred":
+                ts.wait_event(p.ev_lpcsr)
+            with torch.cuda.stream(ts):
+                self._use_stream(ts)
+                self._cur_gemm_ws, self.loss_ws = self.task_gemm_ws[ti], self.task_loss_ws[ti]
+                self._task_head(p, inp, ti, t, hL, gH, sc, T_)
+                ev = torch.cuda.Event(); ev.record(ts)
+                done.append(ev)
+        self._use_stream(main)
+        self._cur_gemm_ws = self.gemm_ws
+        self.loss_ws = self.task_loss_ws[0]
+        for ev in done:
+            main.wait_event(ev)
+        main.wait_event(p.ev_lpcsr)
+        self._backbone_backward(p, inp)
+
+    def _task_head(self, p: StepPlan, inp: StepInputs, ti: int, t: str, hL: Tensor, gH: Tensor, sc: int, T_: float) -> None:
+        """Head forward, loss, and head backward of ONE task (writes its rows of gH and its slots of task_grads)."""
+        lib, st, N, D, P, TG = self.lib, self._st(), p.N, self.domains, self._P, self._TG
+        hd, tg = self.hd, self.task_grads.data_ptr()
+        if True:
             gs = sc + 4 * ti                                        # device scalar 1/size_t: d total_t / d loss_sum
             ls = self.loss_sums.data_ptr() + 4 * ti
             if t == "node_feat_mask":
                 rows, M = p.nfm_rows, p.nfm_rows[-1]
                 if M == 0:
-                    continue
+                    return
                 self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nfm_idx"], None, hd["nfm_in"].data_ptr(), M, N, H, st), "nfm gather")
                 d1 = self._mlp2_grouped(ti, t, hd["nfm_in"], rows, H, H, H, (hd["nfm_y1"], hd["nfm_d1"], hd["nfm_y2"]), 100 + ti)
                 self._chk(lib.gmp_mse_sum_fwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), M * H, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "mse")
@@ -750,15 +841,17 @@ class StepEngine:
                 self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
                 self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
                                                        hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")
+                # reduce the per-edge gradients onto nodes -- only over this task's own rows (other tasks' heads are
+                # writing their rows of gH concurrently on their own streams)
                 c = self.lp_csr
-                self._chk(lib.gmp_csr_build(p.d64["lp_edges"], N, K, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(),
-                                            c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(), self.csr_ws.numel(), st), "lp csr")
-                self._chk(lib.gmp_segment_sum(hd["lp_ghs"].data_ptr(), c[3].data_ptr(), c[5].data_ptr(), gH.data_ptr(), N, H, 0, 1, st), "lp g by src")
-                self._chk(lib.gmp_segment_sum(hd["lp_ghd"].data_ptr(), c[0].data_ptr(), c[2].data_ptr(), gH.data_ptr(), N, H, 0, 1, st), "lp g by dst")
+                r0, r1 = p.task_row[ti], p.task_row[ti + 1]
+                g_rows = gH.data_ptr() + 4 * H * r0
+                self._chk(lib.gmp_segment_sum(hd["lp_ghs"].data_ptr(), c[3].data_ptr() + 4 * r0, c[5].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by src")
+                self._chk(lib.gmp_segment_sum(hd["lp_ghd"].data_ptr(), c[0].data_ptr() + 4 * r0, c[2].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by dst")
             elif t == "node_contrast":
                 rows, M = p.nc_rows, p.nc_rows[-1]
                 if M == 0:
-                    continue
+                    return
                 self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nc_idx"], None, hd["nc_in"].data_ptr(), M, N, H, st), "nc gather")
                 d1 = self._mlp2_grouped(ti, t, hd["nc_in"], rows, H, H, 128, (hd["nc_y1"], hd["nc_d1"], hd["nc_z"]), 100 + ti)
                 self._nt_xent_domains(p.nc_n, rows, hd["nc_z"], hd["nc_gz"], gs, ls, T_, 0)
@@ -767,7 +860,7 @@ class StepEngine:
             elif t == "graph_contrast":
                 rows, B = p.gc_rows, p.gc_B
                 if B == 0:
-                    continue
+                    return
                 self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gc_ptr"], None, hd["gc_mean"].data_ptr(), B, H, 1, 0, st), "gc mean")
                 self._chk(lib.gmp_segment_max_fwd(hL.data_ptr(), p.d32["gc_ptr"], hd["gc_max"].data_ptr(), B, H, st), "gc max")
                 torch.cat([hd["gc_mean"][:B], hd["gc_max"][:B]], dim=1, out=hd["gc_in"][:B])
@@ -790,7 +883,6 @@ class StepEngine:
                 self._mlp2_grouped_bwd(ti, t, hd["gp_in"], rows, H, 2 * H, G, hd["gp_y1"], d1, self.gp_g2, hd["gp_g1"], hd["gp_gin"], 100 + ti)
                 g_rows = gH.data_ptr() + 4 * H * p.gp_r0
                 self._chk(lib.gmp_row_gather(hd["gp_gin"].data_ptr(), p.d64["gp_gid"], p.d32["gp_ptr"], g_rows, p.gp_M, B, H, st), "gp mean bwd")
-        self._backbone_backward(p, inp)
 
     def _nt_xent_domains(self, ns: List[int], rows: List[int], z: Tensor, gz: Tensor, gs: int, ls: int, temperature: float, slot0: int) -> None:
         """One NT-Xent problem per domain on rows [rows[d], rows[d+1]) = [z1 ; z2]; loss sums land in scal[16+slot],
@@ -828,7 +920,7 @@ class StepEngine:
             self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z2[l].data_ptr(), self.h[l].data_ptr(), p.d32["seg_ptr"], None, p.S, p.max_seg, N, H,
                                      P(pre + "batch_norm.weight"), P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(),
                                      self.stat["m2"][l].data_ptr(), self.stat["s2"][l].data_ptr(), gu.data_ptr(), tg, tg, _i32(task_seg),
-                                     _i64([TG(t, pre + "batch_norm.weight") for t in range(T)]), _i64([TG(t, pre + "batch_norm.bias") for t in range(T)]),
+                                     self._TGs(pre + "batch_norm.weight"), self._TGs(pre + "batch_norm.bias"),
                                      T, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2 bwd")
             self._gemm_g(TN, gu.data_ptr(), self.r1[l].data_ptr(), None, tg, trow, None, None, [TG(t, pre + "gin_conv.nn.3.weight") for t in range(T)],
                          tg, [TG(t, pre + "gin_conv.nn.3.bias") for t in range(T)], H, 2 * H, 0, H, 2 * H, 2 * H)
@@ -838,14 +930,14 @@ class StepEngine:
             self._chk(lib.gmp_bn_bwd(self.gW.data_ptr(), self.z1[l].data_ptr(), None, p.d32["seg_ptr"], None, p.S, p.max_seg, N, 2 * H,
                                      P(pre + "gin_conv.nn.1.weight"), P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(),
                                      self.stat["m1"][l].data_ptr(), self.stat["s1"][l].data_ptr(), self.gW2.data_ptr(), tg, tg, _i32(task_seg),
-                                     _i64([TG(t, pre + "gin_conv.nn.1.weight") for t in range(T)]), _i64([TG(t, pre + "gin_conv.nn.1.bias") for t in range(T)]),
+                                     self._TGs(pre + "gin_conv.nn.1.weight"), self._TGs(pre + "gin_conv.nn.1.bias"),
                                      T, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1 bwd")
             self._gemm_g(TN, self.gW2.data_ptr(), self.a[l].data_ptr(), None, tg, trow, None, None, [TG(t, pre + "gin_conv.nn.0.weight") for t in range(T)],
                          tg, [TG(t, pre + "gin_conv.nn.0.bias") for t in range(T)], 2 * H, H, 0, 2 * H, H, H)
             self._gemm(NN, self.gW2.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
             self._chk(lib.gmp_gin_aggregate_bwd_ex(ga.data_ptr(), c[3].data_ptr(), c[4].data_ptr(), P(pre + "gin_conv.eps"), self.h[l].data_ptr(),
                                                    gu.data_ptr(), gcur.data_ptr(), self.rowdot.data_ptr(), N, H, st), "aggregate bwd")
-            self._chk(lib.gmp_group_sum_1d(self.rowdot.data_ptr(), T, _i32(trow), _i64([TG(t, pre + "gin_conv.eps") for t in range(T)]), tg, st), "eps grad")
+            self._chk(lib.gmp_group_sum_1d(self.rowdot.data_ptr(), T, _i32(trow), self._TGs(pre + "gin_conv.eps"), tg, st), "eps grad")
         # ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
         if "node_feat_mask" in self.tasks and p.nfm_rows[-1]:
             ti, M = self.tasks.index("node_feat_mask"), p.nfm_rows[-1]
