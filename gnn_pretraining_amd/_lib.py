@@ -21,9 +21,12 @@ class GnnmpError(RuntimeError):
     pass
 
 
+STEP_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnmp_step.h")
+
+
 def declared_symbols() -> List[str]:
-    """Every function name declared in include/gnnmp.h (used by the export test)."""
-    text = open(HEADER_PATH).read()
+    """Every function name declared in include/gnnmp.h and include/gnnmp_step.h (used by the export test)."""
+    text = open(HEADER_PATH).read() + open(STEP_HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gmp_[a-z0-9_]+)\s*\(", text)))
 
@@ -93,6 +96,8 @@ _SIGS: Dict[str, tuple] = {
     "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),
     "gmp_encoder_fwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, p, p, p, i32, p, p]),
     "gmp_encoder_bwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, i32, p, p, p, p, p, sz, p]),
+    "gmp_step_desc_size": (sz, []),
+    "gmp_pretrain_step_fwd_bwd": (C.c_int, [p, p, p, p]),
     "gmp_mt_workspace_bytes": (sz, [i32]),
     "gmp_mt_pcgrad_clip_adamw": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
                                            f32, p, p, p, p, p, sz, i32, p]),
@@ -107,6 +112,10 @@ def _declare(l: C.CDLL) -> None:
         fn = getattr(l, name)
         fn.restype = res
         fn.argtypes = args
+    from ._step_desc import StepDesc
+    if l.gmp_step_desc_size() != C.sizeof(StepDesc):
+        raise GnnmpError(f"gnnmp_step.h / _step_desc.py disagree: sizeof(gmp_step_desc) = {l.gmp_step_desc_size()} "
+                         f"but the ctypes mirror is {C.sizeof(StepDesc)} bytes")
 
 
 def check(rc: int, what: str) -> None:

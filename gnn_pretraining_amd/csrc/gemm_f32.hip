@@ -17,13 +17,13 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
+constexpr int BK_DEFAULT = 32;
 constexpr int THREADS = 256;
 
 // Load one BK x R operand tile into registers.
 //  KMAJOR=false: memory is [R_total rows][K] (k contiguous, leading dim ld)  -> row-major activations / Linear weights
 //  KMAJOR=true : memory is [K][R_total]      (row index contiguous)          -> already k-major
-template <int R, bool KMAJOR>
+template <int R, bool KMAJOR, int BK>
 struct TileLoader {
     static constexpr int NV = R * BK / 4 / THREADS;   // float4 per thread
     float4 v[NV];
@@ -62,6 +62,33 @@ struct TileLoader {
                 }
             }
             v[s] = x;
+        }
+    }
+
+    // Branch-free variant for the common case (16-B aligned operands, leading dims and extents multiples of 4, and for
+    // k-contiguous operands K a multiple of BK): out-of-range rows are CLAMPED to the last valid row instead of guarded
+    // (their products land in output rows/columns the epilogue never stores), k beyond the reduction range is zeroed
+    // with a select.  One unconditional global_load_dwordx4 per slot -- the guarded generic loader above compiles to
+    // ~50 scalar loads and ~100 branches per K-step.
+    __device__ __forceinline__ void load_fast(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rtot, int64_t k0,
+                                              int64_t K, int t) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int f = t + s * THREADS;
+            if (!KMAJOR) {
+                const int row = f / (BK / 4), kq = f % (BK / 4);
+                int64_t gr = r0 + row;
+                gr = gr < rtot ? gr : rtot - 1;
+                v[s] = *reinterpret_cast<const float4*>(P + gr * ld + k0 + 4 * kq);
+            } else {
+                const int k = f / (R / 4), q = f % (R / 4);
+                const int64_t gk = k0 + k;
+                int64_t gr = r0 + 4 * q;
+                gr = gr + 3 < rtot ? gr : rtot - 4;
+                const float4 x = *reinterpret_cast<const float4*>(P + (gk < K ? gk : K - 1) * ld + gr);
+                const float m = gk < K ? 1.f : 0.f;
+                v[s] = make_float4(x.x * m, x.y * m, x.z * m, x.w * m);
+            }
         }
     }
 
@@ -115,13 +142,14 @@ struct GemmArgs {
     float* gasum_part;
 };
 
-template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
+template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int BK, bool FAST>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
-    using LA = TileLoader<BM, A_KMAJOR>;
-    using LB = TileLoader<BN, B_KMAJOR>;
+    using LA = TileLoader<BM, A_KMAJOR, BK>;
+    using LB = TileLoader<BN, B_KMAJOR, BK>;
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ __attribute__((aligned(16))) float As[BK * LA::LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LB::LD];
+    // two LDS stages: the tile of K-step k+1 is written while step k is multiplied -> one barrier per step
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LB::LD];
 
     const int t = threadIdx.x, lane = t % 64, wv = t / 64;
     const int wm = wv / 2, wn = wv % 2, l31 = lane & 31, half = lane >> 5;
@@ -176,35 +204,44 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
     LA la;
     LB lb;
     if (kbeg < kend) {
-        la.load(g.A, g.lda, m0, Mrows, kbeg, kend, g.vecA, t);
-        lb.load(Bp, g.ldb, n0, g.N, kbeg, kend, g.vecB, t);
+        if (FAST) { la.load_fast(g.A, g.lda, m0, Mrows, kbeg, kend, t); lb.load_fast(Bp, g.ldb, n0, g.N, kbeg, kend, t); }
+        else { la.load(g.A, g.lda, m0, Mrows, kbeg, kend, g.vecA, t); lb.load(Bp, g.ldb, n0, g.N, kbeg, kend, g.vecB, t); }
+        la.store(As[0], t);
+        lb.store(Bs[0], t);
     }
+    __syncthreads();
+    int cur = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        la.store(As, t);
-        lb.store(Bs, t);
-        __syncthreads();
+        const bool more = k0 + BK < kend;
+        if (more) {   // fetch the next K-step while this one is multiplied
+            if (FAST) { la.load_fast(g.A, g.lda, m0, Mrows, k0 + BK, kend, t); lb.load_fast(Bp, g.ldb, n0, g.N, k0 + BK, kend, t); }
+            else { la.load(g.A, g.lda, m0, Mrows, k0 + BK, kend, g.vecA, t); lb.load(Bp, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t); }
+        }
+        const float* __restrict__ Ac = As[cur];
+        const float* __restrict__ Bc = Bs[cur];
         if (want_asum && t < BM) {
 #pragma unroll 8
-            for (int kk = 0; kk < BK; ++kk) colacc += As[kk * LA::LD + t];
-        }
-        if (k0 + BK < kend) {   // prefetch the next K-step while this one is multiplied
-            la.load(g.A, g.lda, m0, Mrows, k0 + BK, kend, g.vecA, t);
-            lb.load(Bp, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, t);
+            for (int kk = 0; kk < BK; ++kk) colacc += Ac[kk * LA::LD + t];
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + half) * LA::LD + wm * (BM / 2) + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * kk + half) * LA::LD + wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + half) * LB::LD + wn * (BN / 2) + j * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * kk + half) * LB::LD + wn * (BN / 2) + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) {
+            la.store(As[cur ^ 1], t);
+            lb.store(Bs[cur ^ 1], t);
+        }
         __syncthreads();
+        cur ^= 1;
     }
 
     if (want_asum && t < BM && m0 + t < Mrows) {
@@ -297,16 +334,31 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[col] = accumulate ? out[col] + s : s;
 }
 
-template <int BM, int BN>
-void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st) {
-    switch (mode) {
-        case GMP_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(THREADS), 0, st, g); break;
-        case GMP_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(THREADS), 0, st, g); break;
-        default:          hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(THREADS), 0, st, g); break;
-    }
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// conditions of TileLoader::load_fast for every operand of this problem
+template <int BK>
+bool fast_ok(int mode, const GemmArgs& g, int64_t min_rows) {
+    if (!g.vecA || !g.vecB) return false;                               // 16-B aligned bases, leading dims % 4 == 0
+    if (mode == GMP_GEMM_NT) return g.K % BK == 0 && g.K > 0 && min_rows >= 1 && g.N >= 1;
+    if (mode == GMP_GEMM_NN) return g.K % BK == 0 && g.K > 0 && min_rows >= 1 && g.N % 4 == 0 && g.N >= 4;
+    return g.M % 4 == 0 && g.M >= 4 && g.N % 4 == 0 && g.N >= 4;       // TN: k range is select-masked, columns clamped by quads
 }
 
-inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+template <int BM, int BN, int BK = BK_DEFAULT>
+void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st, bool fast = false) {
+#define GMP_GEMM_LAUNCH(AK, BKM)                                                                                    \
+    do {                                                                                                           \
+        if (fast) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BKM, BK, true>), grid, dim3(THREADS), 0, st, g);      \
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BKM, BK, false>), grid, dim3(THREADS), 0, st, g);          \
+    } while (0)
+    switch (mode) {
+        case GMP_GEMM_NT: GMP_GEMM_LAUNCH(false, false); break;
+        case GMP_GEMM_NN: GMP_GEMM_LAUNCH(false, true); break;
+        default:          GMP_GEMM_LAUNCH(true, true); break;
+    }
+#undef GMP_GEMM_LAUNCH
+}
 
 }  // namespace
 
@@ -315,9 +367,9 @@ extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, i
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // split-K is used only when the output alone cannot fill the chip and K is long
     const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles >= 256 || K < 8 * BK) return 0;
+    if (tiles >= 256 || K < 8 * BK_DEFAULT) return 0;
     int64_t sk = (512 + tiles - 1) / tiles;
-    const int64_t steps = (K + BK - 1) / BK;
+    const int64_t steps = (K + BK_DEFAULT - 1) / BK_DEFAULT;
     if (sk > steps / 2) sk = steps / 2;
     if (sk < 2) return 0;
     return (size_t)sk * M * N * sizeof(float);
@@ -349,10 +401,15 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
     int tile = 0;
     (void)t12864;
     if (g.splitk == 1) tile = t128 >= 4096 ? 2 : 0;     // measured on MI355X: 64x64 wins until the grid is many waves deep
-    if (forced >= 0 && g.splitk == 1) tile = forced;
-    if (tile == 2) launch_mode<128, 128>(mode, g, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), 1), st);
-    else if (tile == 1) launch_mode<128, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128), 1), st);
-    else launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st);
+    if (forced >= 0 && forced <= 2 && g.splitk == 1) tile = forced;
+    static const bool nofast = getenv("GMP_GEMM_NOFAST") != nullptr;
+    // with split-K (TN) slices start at multiples of BK inside [0,K): the fast loader's k handling covers that
+    const bool fast = !nofast && fast_ok<BK_DEFAULT>(mode, g, M);
+    if (tile == 2) launch_mode<128, 128>(mode, g, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), 1), st, fast);
+    else if (tile == 1) launch_mode<128, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128), 1), st, fast);
+    else if (forced == 3) launch_mode<64, 64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st, !nofast && fast_ok<64>(mode, g, M));
+    else if (forced == 4) launch_mode<64, 64, 16>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st, fast);
+    else launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)g.splitk), st, fast);
     if (int rc = gmp::check_launch("gemm_kernel")) return rc;
     if (g.splitk > 1) {
         int blocks = (int)std::min<int64_t>((M * N + 255) / 256, 2048);
@@ -400,8 +457,8 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         // few output tiles x long reductions: slice every group's rows over several blocks when a workspace is given
         const int64_t tiles = ((N + 63) / 64) * ((g.M + 63) / 64) * groups;
         int split = 1;
-        if (workspace && tiles < 384 && max_rows >= 8 * BK) {
-            split = (int)std::min<int64_t>((512 + tiles - 1) / tiles, max_rows / (4 * BK));
+        if (workspace && tiles < 384 && max_rows >= 8 * BK_DEFAULT) {
+            split = (int)std::min<int64_t>((512 + tiles - 1) / tiles, max_rows / (4 * BK_DEFAULT));
             const size_t need = (size_t)groups * split * (g.M * N + g.M) * sizeof(float);
             if (split < 2 || need > workspace_bytes) split = 1;
         }
@@ -410,7 +467,9 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
             g.gpart = (float*)workspace;
             g.gasum_part = g.gpart + (size_t)groups * split * g.M * N;
         }
-        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(groups * split)), st);
+        static const bool nofast_g = getenv("GMP_GEMM_NOFAST") != nullptr;
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(groups * split)), st,
+                            !nofast_g && fast_ok<BK_DEFAULT>(mode, g, 1));
         if (split > 1) {
             if (int rc = gmp::check_launch("gemm_kernel (grouped, split)")) return rc;
             int blocks = (int)std::min<int64_t>((g.M * N + g.M + 255) / 256, 256);
@@ -419,7 +478,10 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     } else {
         if (max_rows == 0) return GMP_OK;
         g.M = 0;
-        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((max_rows + 63) / 64), (unsigned)groups), st);
+        static const bool nofast_g2 = getenv("GMP_GEMM_NOFAST") != nullptr;
+        g.K = K;
+        launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((max_rows + 63) / 64), (unsigned)groups), st,
+                            !nofast_g2 && fast_ok<BK_DEFAULT>(mode, g, 1));
     }
     return gmp::check_launch("gemm_kernel (grouped)");
 }

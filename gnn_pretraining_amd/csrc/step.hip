@@ -1,0 +1,301 @@
+// Whole-step executor: stacked forward, the five task heads (each on its own stream) and the stacked
+// backward of one pre-training step, enqueued from C++ so the host crosses the FFI once.  It is a
+// transcription of gnn_pretraining_amd/engine.py (_forward, _task_head, _backbone_backward): same entry
+// points, same order, same buffers -> bitwise the same result (tests/test_gpu_engine.py).
+#include "../../include/gnnmp_step.h"
+#include "gnnmp_internal.h"
+
+namespace {
+
+#define GMP_TRY(expr)                \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != GMP_OK) return _rc; \
+    } while (0)
+
+constexpr int H = 256;
+constexpr int NEV = 2 + GMP_STEP_MAX_TASKS + 2;
+
+hipEvent_t* events() {   // one process drives one engine: a small static pool of timing-free events
+    static hipEvent_t ev[NEV];
+    static bool made = false;
+    if (!made) {
+        for (int i = 0; i < NEV; ++i) (void)hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        made = true;
+    }
+    return ev;
+}
+
+gmp_bn_config bn_cfg(const gmp_step_desc& d, bool relu, bool dropout, uint32_t site) {
+    gmp_bn_config c;
+    c.training = d.training;
+    c.relu = relu;
+    c.eps = 1e-5f;
+    c.momentum = 0.1f;
+    c.dropout_p = (dropout && d.training) ? d.dropout_p : 0.f;
+    c.seed = d.seed;
+    c.stream_id = site;
+    return c;
+}
+
+int gemm(int mode, const float* A, const float* B, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+         int64_t ldb, int64_t ldc, bool relu, gmp_stream_t st) {
+    return gmp_gemm_f32(mode, A, B, bias, C, M, N, K, lda, ldb, ldc, 1.f, 0, relu ? 1 : 0, nullptr, 0, st);
+}
+
+// dropout(src) -> dst, or alias src when dropout is off; returns the buffer holding the result
+float* drop(const gmp_step_desc& d, float* src, float* dst, int64_t numel, uint32_t site, gmp_stream_t st, int* rc) {
+    *rc = GMP_OK;
+    if (!d.training || d.dropout_p <= 0.f) return src;
+    *rc = gmp_dropout_fwd(src, dst, numel, d.dropout_p, d.seed, site, st);
+    return dst;
+}
+
+int mlp2_fwd(const gmp_step_desc& d, const gmp_task_desc& t, float** d1_out, gmp_stream_t st) {
+    const gmp_mlp2& m = t.mlp;
+    const int G = d.num_domains;
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NT, m.x, d.flat, d.flat, m.y1, G, m.rows, m.off_w0, m.off_b0, nullptr, nullptr, nullptr, 0,
+                                 m.k_hid, m.k_in, m.k_in, m.k_in, m.k_hid, 1.f, 0, 1, nullptr, 0, st));
+    int rc;
+    float* d1 = drop(d, m.y1, m.d1, (int64_t)m.rows[G] * m.k_hid, m.site, st, &rc);
+    GMP_TRY(rc);
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NT, d1, d.flat, d.flat, m.y2, G, m.rows, m.off_w3, m.off_b3, nullptr, nullptr, nullptr, 0,
+                                 m.k_out, m.k_hid, m.k_hid, m.k_hid, m.k_out, 1.f, 0, 0, nullptr, 0, st));
+    *d1_out = d1;
+    return GMP_OK;
+}
+
+int mlp2_bwd(const gmp_step_desc& d, const gmp_task_desc& t, float* d1, gmp_stream_t st) {
+    const gmp_mlp2& m = t.mlp;
+    const int G = d.num_domains;
+    float* tg = d.task_grads;
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_out, d1, nullptr, tg, G, m.rows, nullptr, nullptr, m.tg_w3, tg, m.tg_b3, m.k_out, m.k_hid, 0,
+                                 m.k_out, m.k_hid, m.k_hid, 1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_out, d.flat, nullptr, m.g_hid, G, m.rows, m.off_w3, nullptr, nullptr, nullptr, nullptr, 0,
+                                 m.k_hid, m.k_out, m.k_out, m.k_hid, m.k_hid, 1.f, 0, 0, nullptr, 0, st));
+    GMP_TRY(gmp_relu_dropout_bwd(m.g_hid, m.y1, m.g_hid, (int64_t)m.rows[G] * m.k_hid, d.training ? d.dropout_p : 0.f, d.seed, m.site, st));
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_hid, m.x, nullptr, tg, G, m.rows, nullptr, nullptr, m.tg_w0, tg, m.tg_b0, m.k_hid, m.k_in, 0,
+                                 m.k_hid, m.k_in, m.k_in, 1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_hid, d.flat, nullptr, m.g_in, G, m.rows, m.off_w0, nullptr, nullptr, nullptr, nullptr, 0,
+                                 m.k_in, m.k_hid, m.k_hid, m.k_in, m.k_in, 1.f, 0, 0, nullptr, 0, st));
+    return GMP_OK;
+}
+
+int nt_xent_domains(const gmp_step_desc& d, const gmp_task_desc& t, float* z, float* gz, gmp_stream_t st) {
+    const gmp_mlp2& m = t.mlp;
+    for (int di = 0; di < d.num_domains; ++di) {
+        const int n = t.ntx_n[di];
+        if (n == 0) continue;
+        float* z1 = z + (int64_t)128 * m.rows[di];
+        float* z2 = z1 + (int64_t)128 * n;
+        GMP_TRY(gmp_nt_xent_fwd(z1, z2, n, 128, t.temperature, t.ntx_sums + di, t.ntx_ws[di], t.ntx_ws_bytes[di], st));
+        float* g1 = gz + (int64_t)128 * m.rows[di];
+        GMP_TRY(gmp_nt_xent_bwd(z1, z2, n, 128, t.temperature, t.g_scale, g1, g1 + (int64_t)128 * n, t.ntx_ws[di], t.ntx_ws_bytes[di], st));
+    }
+    const int32_t rows[2] = {0, d.num_domains};
+    const int64_t off[1] = {0};
+    return gmp_group_sum_1d(t.ntx_sums, 1, rows, off, t.loss_sum, st);
+}
+
+int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
+    const gmp_task_desc& t = d.task[ti];
+    const gmp_mlp2& m = t.mlp;
+    const int64_t N = d.N;
+    float* hL = d.h[GMP_STEP_LAYERS];
+    float* gH = d.gA;
+    float* tg = d.task_grads;
+    float* d1 = nullptr;
+    switch (t.kind) {
+        case GMP_TASK_NFM: {
+            const int64_t M = t.num_idx;
+            if (M == 0) return GMP_OK;
+            GMP_TRY(gmp_row_gather(hL, t.idx, nullptr, m.x, M, N, H, st));
+            GMP_TRY(mlp2_fwd(d, t, &d1, st));
+            GMP_TRY(gmp_mse_sum_fwd(m.y2, t.nfm_target, M * H, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gmp_mse_sum_bwd(m.y2, t.nfm_target, t.g_scale, m.g_out, M * H, st));
+            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            return gmp_row_fill(gH, t.idx, m.g_in, M, N, H, 0, st);
+        }
+        case GMP_TASK_LP: {
+            const int64_t K = t.lp_K;
+            const float *w0 = d.flat + t.lp_off_w0, *b0 = d.flat + t.lp_off_b0, *w3 = d.flat + t.lp_off_w3, *b3 = d.flat + t.lp_off_b3;
+            GMP_TRY(gmp_lp_edge_features_fwd(hL, t.lp_edges, t.lp_feat, N, K, H, st));
+            GMP_TRY(gemm(GMP_GEMM_NT, t.lp_feat, w0, b0, t.lp_y1, K, H, 3 * H, 3 * H, 3 * H, H, true, st));
+            int rc;
+            float* ld1 = drop(d, t.lp_y1, t.lp_d1, K * H, t.lp_site, st, &rc);
+            GMP_TRY(rc);
+            GMP_TRY(gemm(GMP_GEMM_NT, ld1, w3, b3, t.lp_y2, K, 1, H, H, H, 1, false, st));
+            GMP_TRY(gmp_sigmoid_fwd(t.lp_y2, t.lp_p, K, st));
+            GMP_TRY(gmp_bce_sum_fwd(t.lp_p, t.lp_labels, K, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gmp_bce_sum_bwd(t.lp_p, t.lp_labels, t.g_scale, t.lp_gp, K, st));
+            GMP_TRY(gmp_sigmoid_bwd(t.lp_gp, t.lp_p, t.lp_gy2, K, st));
+            const int32_t one[2] = {0, (int32_t)K};
+            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3};
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy2, ld1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, 1, H, 0, 1, H, H, 1.f, 0, 0,
+                                         t.gemm_ws, t.gemm_ws_bytes, st));
+            GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy2, w3, nullptr, t.lp_gy1, K, H, 1, 1, H, H, false, st));
+            GMP_TRY(gmp_relu_dropout_bwd(t.lp_gy1, t.lp_y1, t.lp_gy1, K * H, d.training ? d.dropout_p : 0.f, d.seed, t.lp_site, st));
+            size_t wsb = gmp_gemm_f32_workspace_bytes(GMP_GEMM_TN, H, 3 * H, K);
+            if (wsb > (size_t)K * 3 * H * sizeof(float)) wsb = 0;     // lp_gfeat doubles as the split-K scratch before it is written
+            GMP_TRY(gmp_gemm_f32(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg + t.lp_tg_w0, H, 3 * H, K, H, 3 * H, 3 * H, 1.f, 0, 0,
+                                 wsb ? t.lp_gfeat : nullptr, wsb, st));
+            GMP_TRY(gmp_colsum(t.lp_gy1, tg + t.lp_tg_b0, K, H, H, 0, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy1, w0, nullptr, t.lp_gfeat, K, 3 * H, H, H, 3 * H, 3 * H, false, st));
+            GMP_TRY(gmp_lp_edge_features_bwd(t.lp_gfeat, hL, t.lp_edges, t.lp_ghs, t.lp_ghd, N, K, H, st));
+            float* g_rows = gH + (int64_t)H * t.row0;
+            GMP_TRY(gmp_segment_sum(t.lp_ghs, d.lp_csr[3] + t.row0, d.lp_csr[5], g_rows, t.row1 - t.row0, H, 0, 1, st));
+            return gmp_segment_sum(t.lp_ghd, d.lp_csr[0] + t.row0, d.lp_csr[2], g_rows, t.row1 - t.row0, H, 0, 1, st);
+        }
+        case GMP_TASK_NC: {
+            const int64_t M = t.num_idx;
+            if (M == 0) return GMP_OK;
+            GMP_TRY(gmp_row_gather(hL, t.idx, nullptr, m.x, M, N, H, st));
+            GMP_TRY(mlp2_fwd(d, t, &d1, st));
+            GMP_TRY(nt_xent_domains(d, t, m.y2, m.g_out, st));
+            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            return gmp_row_fill(gH, t.idx, m.g_in, M, N, H, 0, st);
+        }
+        case GMP_TASK_GC: {
+            const int B = t.pool_B;
+            if (B == 0) return GMP_OK;
+            GMP_TRY(gmp_segment_sum(hL, t.pool_ptr, nullptr, t.pool_mean, B, H, 1, 0, st));
+            GMP_TRY(gmp_segment_max_fwd(hL, t.pool_ptr, t.pool_max, B, H, st));
+            // [mean | max] -> x [B, 512]
+            if (hipMemcpy2DAsync(m.x, 2 * H * sizeof(float), t.pool_mean, H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)st) != hipSuccess ||
+                hipMemcpy2DAsync(m.x + H, 2 * H * sizeof(float), t.pool_max, H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)st) != hipSuccess)
+                return gmp::fail(GMP_ERR_LAUNCH, "step: read-out concat copy failed");
+            GMP_TRY(mlp2_fwd(d, t, &d1, st));
+            GMP_TRY(nt_xent_domains(d, t, m.y2, m.g_out, st));
+            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            if (hipMemcpy2DAsync(t.g_mean, H * sizeof(float), m.g_in, 2 * H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)st) != hipSuccess ||
+                hipMemcpy2DAsync(t.g_max, H * sizeof(float), m.g_in + H, 2 * H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)st) != hipSuccess)
+                return gmp::fail(GMP_ERR_LAUNCH, "step: read-out split copy failed");
+            GMP_TRY(gmp_row_gather(t.g_mean, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st));
+            return gmp_segment_max_bwd(t.g_max, hL, t.pool_max, t.pool_ptr, gH, B, H, 1, st);
+        }
+        case GMP_TASK_GP: {
+            const int B = t.pool_B;
+            GMP_TRY(gmp_segment_sum(hL, t.pool_ptr, nullptr, m.x, B, H, 1, 0, st));
+            GMP_TRY(mlp2_fwd(d, t, &d1, st));
+            GMP_TRY(gmp_mse_sum_fwd(m.y2, t.labels, (int64_t)B * m.k_out, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gmp_mse_sum_bwd(m.y2, t.labels, t.g_scale, m.g_out, (int64_t)B * m.k_out, st));
+            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            return gmp_row_gather(m.g_in, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st);
+        }
+        default:
+            return gmp::fail(GMP_ERR_ARG, "step: unknown task kind %d", t.kind);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gmp_step_desc_size(void) { return sizeof(gmp_step_desc); }
+
+extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t main_, const gmp_stream_t* task_streams, gmp_stream_t aux_) {
+    if (!dp || !task_streams) return gmp::fail(GMP_ERR_ARG, "step: null descriptor");
+    const gmp_step_desc& d = *dp;
+    if (d.hidden != H || d.num_tasks < 1 || d.num_tasks > GMP_STEP_MAX_TASKS || d.num_domains < 1 || d.num_domains > GMP_STEP_MAX_DOMAINS ||
+        d.N <= 0 || d.S <= 0 || d.enc_groups < 0 || d.enc_groups > GMP_STEP_MAX_ENC_GROUPS)
+        return gmp::fail(GMP_ERR_ARG, "step: bad sizes (N=%d S=%d tasks=%d domains=%d hidden=%d)", d.N, d.S, d.num_tasks, d.num_domains, d.hidden);
+    hipStream_t main = (hipStream_t)main_, aux = (hipStream_t)aux_;
+    hipEvent_t* ev = events();
+    const int64_t N = d.N;
+    const int T = d.num_tasks;
+    float* tg = d.task_grads;
+
+    // ---- CSR builds beside the encoders (they only need the uploaded indices)
+    (void)hipEventRecord(ev[0], main);
+    (void)hipStreamWaitEvent(aux, ev[0], 0);
+    GMP_TRY(gmp_csr_build(d.edge_index, N, d.E, d.csr[0], d.csr[1], d.csr[2], d.csr[3], d.csr[4], d.csr[5], d.csr_status, d.csr_ws, d.csr_ws_bytes, aux_));
+    (void)hipEventRecord(ev[1], aux);
+    int lp_task = -1;
+    for (int ti = 0; ti < T; ++ti)
+        if (d.task[ti].kind == GMP_TASK_LP) lp_task = ti;
+    if (lp_task >= 0) {
+        const gmp_task_desc& t = d.task[lp_task];
+        GMP_TRY(gmp_csr_build(t.lp_edges, N, t.lp_K, d.lp_csr[0], d.lp_csr[1], d.lp_csr[2], d.lp_csr[3], d.lp_csr[4], d.lp_csr[5], d.lp_csr_status,
+                              d.lp_csr_ws, d.lp_csr_ws_bytes, aux_));
+    }
+    (void)hipEventRecord(ev[2], aux);
+
+    // ---- encoders
+    GMP_TRY(gmp_encoder_fwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, d.tiles, d.num_tiles, d.flat,
+                            d.num_domains, d.enc_off_w, d.enc_off_b, d.enc_d_in, d.dpad, d.z0, main_));
+    gmp_bn_config c = bn_cfg(d, true, true, 1);
+    GMP_TRY(gmp_bn_fwd(d.z0, nullptr, d.seg_ptr, d.seg_dom, d.S, d.max_seg, N, H, d.flat + d.enc_off_gamma0, d.flat + d.enc_off_beta0, d.enc_rm,
+                       d.enc_rv, d.enc_mean, d.enc_rstd, d.h[0], &c, d.bn_ws, d.bn_ws_bytes, main_));
+    if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {
+        const gmp_task_desc& t = d.task[d.nfm_task];
+        GMP_TRY(gmp_row_gather(d.h[0], t.idx, nullptr, t.nfm_target, t.num_idx, N, H, main_));
+        GMP_TRY(gmp_row_fill(d.h[0], t.idx, d.flat + d.off_mask_token, t.num_idx, N, H, 1, main_));
+    }
+    (void)hipStreamWaitEvent(main, ev[1], 0);
+
+    // ---- stacked backbone forward
+    for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
+        const gmp_layer_desc& L = d.layer[l];
+        GMP_TRY(gmp_gin_aggregate_fwd(d.h[l], d.csr[0], d.csr[1], d.flat + L.off_eps, L.a, N, H, main_));
+        GMP_TRY(gemm(GMP_GEMM_NT, L.a, d.flat + L.off_w1, d.flat + L.off_b1, L.z1, N, 2 * H, H, H, H, 2 * H, false, main_));
+        c = bn_cfg(d, true, false, 0);
+        GMP_TRY(gmp_bn_fwd(L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1, L.s1,
+                           L.r1, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        GMP_TRY(gemm(GMP_GEMM_NT, L.r1, d.flat + L.off_w2, d.flat + L.off_b2, L.z2, N, H, 2 * H, 2 * H, 2 * H, H, false, main_));
+        c = bn_cfg(d, true, true, 10 + l);
+        GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2,
+                           d.h[l + 1], &c, d.bn_ws, d.bn_ws_bytes, main_));
+    }
+
+    // ---- task heads, each on its own stream
+    if (hipMemsetAsync(d.gA, 0, (size_t)N * H * sizeof(float), main) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step: memset");
+    (void)hipEventRecord(ev[3], main);
+    for (int ti = 0; ti < T; ++ti) {
+        hipStream_t ts = (hipStream_t)task_streams[ti];
+        if (ts != main) (void)hipStreamWaitEvent(ts, ev[3], 0);
+        if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
+        GMP_TRY(task_head(d, ti, task_streams[ti]));
+        if (ts != main) {
+            (void)hipEventRecord(ev[4 + ti], ts);
+            (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
+        }
+    }
+    (void)hipStreamWaitEvent(main, ev[2], 0);
+
+    // ---- stacked backbone backward: per-task parameter gradients from ONE pass
+    float *gcur = d.gA, *gu = d.gB, *ga = d.h[GMP_STEP_LAYERS];
+    for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
+        const gmp_layer_desc& L = d.layer[l];
+        c = bn_cfg(d, true, true, 10 + l);
+        GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
+                           tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
+                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, main_));
+        GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
+        c = bn_cfg(d, true, false, 0);
+        GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
+                           L.s1, d.gW2, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, d.gW2, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
+                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, main_));
+        GMP_TRY(gemm(GMP_GEMM_NN, d.gW2, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
+        GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
+        GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
+    }
+    // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
+    if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {
+        const gmp_task_desc& t = d.task[d.nfm_task];
+        GMP_TRY(gmp_row_gather(gcur, t.idx, nullptr, t.mlp.x, t.num_idx, N, H, main_));
+        GMP_TRY(gmp_colsum(t.mlp.x, tg + d.tg_mask_token, t.num_idx, H, H, 0, d.loss_ws, d.loss_ws_bytes, main_));
+    }
+    if (d.enc_groups > 0) {
+        c = bn_cfg(d, true, true, 1);
+        GMP_TRY(gmp_bn_bwd(gcur, d.z0, nullptr, d.seg_ptr, d.seg_dom, d.S, d.max_seg, N, H, d.flat + d.enc_off_gamma0, d.flat + d.enc_off_beta0, d.enc_rm,
+                           d.enc_rv, d.enc_mean, d.enc_rstd, gu, tg, tg, d.enc_gseg, d.enc_tg_gamma, d.enc_tg_beta, d.enc_groups, &c, d.bn_ws,
+                           d.bn_ws_bytes, main_));
+        GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
+                                d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
+    }
+    return GMP_OK;
+}

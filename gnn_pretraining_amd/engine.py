@@ -107,7 +107,8 @@ class ViewArrays:
 class StepEngine:
     def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
-                 grad_sync=None, rng_mode: str = "reference") -> None:
+                 grad_sync=None, rng_mode: str = "reference", native: bool = True) -> None:
+        self.native = native       # True: csrc/step.hip enqueues the step; False: the same launches one by one from Python
         if rng_mode not in ("reference", "vectorized"):
             raise ValueError("rng_mode must be 'reference' or 'vectorized'")
         self.rng_mode, self._nprng = rng_mode, None
@@ -583,8 +584,11 @@ class StepEngine:
         t2 = _t.perf_counter()
         self._upload(p, inp, art)
         t3 = _t.perf_counter()
-        self._forward(p, inp)
-        self._heads_and_backward(p, inp)
+        if self.native:
+            self._forward_backward_native(p, inp)        # one C call enqueues the whole forward/heads/backward
+        else:
+            self._forward(p, inp)
+            self._heads_and_backward(p, inp)
         self._optimizer(p, order, apply_update)
         t4 = _t.perf_counter()
         h = self.host_ms
@@ -1023,3 +1027,173 @@ class StepEngine:
     def final_gradient(self, name: str) -> Tensor:
         o = self.off[name]
         return self.final_grad[o:o + self.numel[name]].view_as(dict(self.model.named_parameters())[name])
+
+    # ---- native executor: the same sequence enqueued by one C call (csrc/step.hip) ---------------------
+    def _init_desc(self):
+        from ._step_desc import StepDesc, TASK_KIND
+        d = StepDesc()
+        D, T = self.domains, self.T
+        ptr = lambda t: t.data_ptr()
+        d.num_tasks, d.num_domains, d.dpad, d.hidden = T, len(D), self.dpad, H
+        d.flat, d.P, d.task_grads = ptr(self.flat), self.P, ptr(self.task_grads)
+        for i in range(6):
+            d.csr[i], d.lp_csr[i] = ptr(self.csr[i]), ptr(self.lp_csr[i])
+        d.csr_status, d.csr_ws, d.csr_ws_bytes = ptr(self.csr_status), ptr(self.csr_ws), self.csr_ws.numel()
+        d.lp_csr_status, d.lp_csr_ws, d.lp_csr_ws_bytes = ptr(self.lp_csr_status), ptr(self.lp_csr_ws), self.lp_csr_ws.numel()
+        for i, dom in enumerate(D):
+            d.enc_off_w[i] = self.off[f"input_encoders.{dom}.linear.weight"]
+            d.enc_off_b[i] = self.off[f"input_encoders.{dom}.linear.bias"]
+            d.enc_d_in[i] = DOMAIN_DIMENSIONS[dom]
+        d.enc_off_gamma0 = self.off[f"input_encoders.{D[0]}.batch_norm.weight"]
+        d.enc_off_beta0 = self.off[f"input_encoders.{D[0]}.batch_norm.bias"]
+        d.enc_rm, d.enc_rv, d.enc_mean, d.enc_rstd, d.z0 = ptr(self.enc_rm), ptr(self.enc_rv), ptr(self.enc_mean), ptr(self.enc_rstd), ptr(self.z0)
+        d.nfm_task = self.tasks.index("node_feat_mask") if "node_feat_mask" in self.tasks else -1
+        if d.nfm_task >= 0:
+            d.off_mask_token, d.tg_mask_token = self.off["mask_token"], self._TG(d.nfm_task, "mask_token")
+        for l in range(GNN_NUM_LAYERS + 1):
+            d.h[l] = ptr(self.h[l])
+        names = {"eps": "gin_conv.eps", "w1": "gin_conv.nn.0.weight", "b1": "gin_conv.nn.0.bias", "g1": "gin_conv.nn.1.weight",
+                 "be1": "gin_conv.nn.1.bias", "w2": "gin_conv.nn.3.weight", "b2": "gin_conv.nn.3.bias", "g2": "batch_norm.weight", "be2": "batch_norm.bias"}
+        for l in range(GNN_NUM_LAYERS):
+            Ld, pre, layer = d.layer[l], f"gnn_backbone.layers.{l}.", self.model.gnn_backbone.layers[l]
+            for k, n in names.items():
+                setattr(Ld, "off_" + k, self.off[pre + n])
+                arr = getattr(Ld, "tg_" + k)
+                for t in range(T):
+                    arr[t] = self._TG(t, pre + n)
+            bn1, bn2 = layer.gin_conv.nn[1], layer.batch_norm
+            Ld.rm1, Ld.rv1, Ld.rm2, Ld.rv2 = ptr(bn1.running_mean), ptr(bn1.running_var), ptr(bn2.running_mean), ptr(bn2.running_var)
+            Ld.a, Ld.z1, Ld.r1, Ld.z2 = ptr(self.a[l]), ptr(self.z1[l]), ptr(self.r1[l]), ptr(self.z2[l])
+            Ld.m1, Ld.s1, Ld.m2, Ld.s2 = ptr(self.stat["m1"][l]), ptr(self.stat["s1"][l]), ptr(self.stat["m2"][l]), ptr(self.stat["s2"][l])
+        d.gA, d.gB, d.gW, d.gW2, d.rowdot = ptr(self.gA), ptr(self.gB), ptr(self.gW), ptr(self.gW2), ptr(self.rowdot)
+        d.bn_ws, d.bn_ws_bytes = ptr(self.bn_ws), self.bn_ws.numel()
+        d.gemm_ws, d.gemm_ws_bytes = ptr(self.gemm_ws), self.gemm_ws.numel()
+        d.loss_ws, d.loss_ws_bytes = ptr(self.task_loss_ws[0]), self.task_loss_ws[0].numel()
+        hd = self.hd
+        mlp_cfg = {"node_feat_mask": (H, H, H, "nfm_in", "nfm_y1", "nfm_d1", "nfm_y2", "nfm_g", "nfm_g1", "nfm_y2"),
+                   "node_contrast": (H, H, 128, "nc_in", "nc_y1", "nc_d1", "nc_z", "nc_gz", "nc_g1", "nc_gin"),
+                   "graph_contrast": (2 * H, H, 128, "gc_in", "gc_y1", "gc_d1", "gc_z", "gc_gz", "gc_g1", "gc_gin"),
+                   "graph_prop": (H, 2 * H, GRAPH_PROPERTY_DIM, "gp_in", "gp_y1", "gp_d1", None, None, "gp_g1", "gp_gin")}
+        sc = ptr(self.scal)
+        for ti, t in enumerate(self.tasks):
+            td = d.task[ti]
+            td.kind = TASK_KIND[t]
+            td.g_scale, td.loss_sum = sc + 4 * ti, ptr(self.loss_sums) + 4 * ti
+            td.gemm_ws, td.gemm_ws_bytes = ptr(self.task_gemm_ws[ti]), self.task_gemm_ws[ti].numel()
+            td.loss_ws, td.loss_ws_bytes = ptr(self.task_loss_ws[ti]), self.task_loss_ws[ti].numel()
+            if t in mlp_cfg:
+                k_in, k_hid, k_out, x, y1, d1, y2, g_out, g_hid, g_in = mlp_cfg[t]
+                m = td.mlp
+                m.k_in, m.k_hid, m.k_out, m.site = k_in, k_hid, k_out, 100 + ti
+                for i, dom in enumerate(D):
+                    for a, n in (("w0", "mlp.0.weight"), ("b0", "mlp.0.bias"), ("w3", "mlp.3.weight"), ("b3", "mlp.3.bias")):
+                        full = f"heads.{t}.{dom}.{n}"
+                        getattr(m, "off_" + a)[i] = self.off[full]
+                        getattr(m, "tg_" + a)[i] = self._TG(ti, full)
+                m.x, m.y1, m.d1, m.g_hid, m.g_in = ptr(hd[x]), ptr(hd[y1]), ptr(hd[d1]), ptr(hd[g_hid]), ptr(hd[g_in])
+                m.y2 = ptr(self.gp_y2) if t == "graph_prop" else ptr(hd[y2])
+                m.g_out = ptr(self.gp_g2) if t == "graph_prop" else ptr(hd[g_out])
+            if t == "node_feat_mask":
+                td.nfm_target = ptr(hd["nfm_tgt"])
+            if t in ("node_contrast", "graph_contrast"):
+                td.ntx_sums = sc + 4 * (16 + (0 if t == "node_contrast" else self.D))
+            if t == "graph_contrast":
+                td.pool_mean, td.pool_max, td.g_mean, td.g_max = ptr(hd["gc_mean"]), ptr(hd["gc_max"]), ptr(hd["gc_gmean"]), ptr(hd["gc_gmax"])
+            if t == "link_pred":
+                td.lp_labels = ptr(self.lp_lab)
+                for a in ("feat", "y1", "d1", "gy1", "gfeat", "ghs", "ghd"):
+                    setattr(td, "lp_" + a, ptr(hd["lp_" + a]))
+                td.lp_y2, td.lp_p, td.lp_gp, td.lp_gy2 = ptr(self.lp_y2), ptr(self.lp_p), ptr(self.lp_gp), ptr(self.lp_gy2)
+                for a, n in (("w0", "mlp.0.weight"), ("b0", "mlp.0.bias"), ("w3", "mlp.3.weight"), ("b3", "mlp.3.bias")):
+                    full = f"heads.link_pred.predictor.{n}"
+                    setattr(td, "lp_off_" + a, self.off[full])
+                    setattr(td, "lp_tg_" + a, self._TG(ti, full))
+                td.lp_site = 100 + ti
+        self._desc = d
+        self._stream_arr = (C.c_void_p * self.T)(*[s.cuda_stream for s in self.task_streams])
+        return d
+
+    def _fill_desc(self, p: StepPlan, inp: StepInputs):
+        d = getattr(self, "_desc", None) or self._init_desc()
+        D = self.domains
+        d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
+        d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
+        d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
+        d.seg_ptr, d.seg_dom, d.src_row, d.tiles = p.d32["seg_ptr"], p.d32["seg_dom"], p.d32["src_row"], p.d32["tiles"]
+        d.edge_index, d.rowmask = p.d64["edge_index"], p.d64.get("rowmask")
+        for i, v in enumerate(p.task_row):
+            d.task_row[i] = v
+        c = 0
+        d.task_seg[0] = 0
+        for ti in range(self.T):
+            c += sum(1 for s in p.seg_task if s == ti)
+            d.task_seg[ti + 1] = c
+        d.x_all, d.x_rows = inp.x_all.data_ptr(), inp.x_all.size(0)
+        groups = self._encoder_groups(p)
+        d.enc_groups = len(groups)
+        if groups:
+            d.enc_gseg[0] = groups[0][2]
+            for g, (ti, dom, lo, hi) in enumerate(groups):
+                d.enc_gseg[g + 1] = hi
+                d.enc_tg_w[g], d.enc_tg_b[g] = self._TG(ti, f"input_encoders.{dom}.linear.weight"), self._TG(ti, f"input_encoders.{dom}.linear.bias")
+                d.enc_tg_gamma[g], d.enc_tg_beta[g] = self._TG(ti, f"input_encoders.{dom}.batch_norm.weight"), self._TG(ti, f"input_encoders.{dom}.batch_norm.bias")
+        T_ = float(self.temperature)
+        for ti, t in enumerate(self.tasks):
+            td = d.task[ti]
+            td.row0, td.row1 = p.task_row[ti], p.task_row[ti + 1]
+            rows = {"node_feat_mask": getattr(p, "nfm_rows", None), "node_contrast": getattr(p, "nc_rows", None),
+                    "graph_contrast": getattr(p, "gc_rows", None), "graph_prop": getattr(p, "gp_rows", None)}.get(t)
+            if rows is not None:
+                for i, v in enumerate(rows):
+                    td.mlp.rows[i] = v
+            if t == "node_feat_mask":
+                td.idx, td.num_idx = p.d64["nfm_idx"], p.nfm_rows[-1]
+            elif t == "node_contrast":
+                td.idx, td.num_idx = p.d64["nc_idx"], p.nc_rows[-1]
+            if t in ("node_contrast", "graph_contrast"):
+                ns, slot0 = (p.nc_n, 0) if t == "node_contrast" else (p.gc_n, self.D)
+                td.temperature = T_
+                for di, n in enumerate(ns):
+                    td.ntx_n[di] = n
+                    if n:
+                        need = self.lib.gmp_nt_xent_workspace_bytes(n, 128)
+                        if need > self.ntx_ws[slot0 + di].numel():
+                            self.ntx_ws[slot0 + di] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                    td.ntx_ws[di], td.ntx_ws_bytes[di] = self.ntx_ws[slot0 + di].data_ptr(), self.ntx_ws[slot0 + di].numel()
+            if t == "graph_contrast":
+                td.pool_ptr, td.pool_gid, td.pool_B, td.pool_r0, td.pool_M = p.d32["gc_ptr"], p.d64["gc_gid"], p.gc_B, p.gc_r0, p.gc_M
+            if t == "graph_prop":
+                td.pool_ptr, td.pool_gid, td.pool_B, td.pool_r0, td.pool_M = p.d32["gp_ptr"], p.d64["gp_gid"], p.gp_B, p.gp_r0, p.gp_M
+                td.labels = inp.graph_props.data_ptr()
+            if t == "link_pred":
+                td.lp_K, td.lp_edges = p.lp_K, p.d64["lp_edges"]
+        return d
+
+    def _encoder_groups(self, p: StepPlan):
+        """(task index, domain, first segment, one-past-last segment) for every (task, domain) pair whose encoder receives a
+        gradient this step; pairs that dropped out get their gradient slots zeroed."""
+        seg_of: Dict[Tuple[int, int], List[int]] = {}
+        for si, (tt, dd) in enumerate(zip(p.seg_task, p.seg_dom)):
+            seg_of.setdefault((tt, dd), []).append(si)
+        groups = []
+        for ti, t in enumerate(self.tasks):
+            if t == "node_feat_mask":
+                continue
+            for di, dom in enumerate(self.domains):
+                segs = seg_of.get((ti, di), [])
+                if not segs:
+                    for key in ("linear.weight", "linear.bias", "batch_norm.weight", "batch_norm.bias"):
+                        n = f"input_encoders.{dom}.{key}"
+                        self.task_grads[ti, self.off[n]:self.off[n] + self.numel[n]].zero_()
+                    continue
+                groups.append((ti, dom, segs[0], segs[-1] + 1))
+        for a, b in zip(groups[:-1], groups[1:]):
+            if a[3] != b[2]:
+                raise L.GnnmpError("engine: encoder gradient groups are not contiguous (segments must be task-major)")
+        return groups
+
+    def _forward_backward_native(self, p: StepPlan, inp: StepInputs) -> None:
+        d = self._fill_desc(p, inp)
+        main = torch.cuda.current_stream(self.device)
+        self._chk(self.lib.gmp_pretrain_step_fwd_bwd(C.byref(d), main.cuda_stream, self._stream_arr, self.aux_stream.cuda_stream),
+                  "gmp_pretrain_step_fwd_bwd")

@@ -1,0 +1,117 @@
+/*
+ * libgnnmp -- whole-step entry point: the stacked forward + task heads + stacked backward of one
+ * pre-training step (reference src/pretrain/pretrain.py:113-150 over src/pretrain/tasks.py) enqueued by ONE C
+ * call, so the host pays one FFI crossing instead of ~300.  It issues exactly the kernel sequence
+ * gnn_pretraining_amd/engine.py issues through the per-operator entry points of gnnmp.h (the Python sequence stays
+ * as the tested reference: tests/test_gpu_engine.py checks the two give bitwise-identical parameters).
+ *
+ * All pointers are device pointers unless the field says "host".  Offsets "off_*" are in floats into `flat`
+ * (parameters) and "tg_*" in floats into `task_grads` ([tasks][P] per-task gradients).  The descriptor is plain
+ * data: fill it, call gmp_pretrain_step_fwd_bwd, then all-reduce task_grads if data-parallel, then
+ * gmp_mt_pcgrad_clip_adamw.
+ */
+#ifndef GNNMP_STEP_H
+#define GNNMP_STEP_H
+
+#include "gnnmp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMP_STEP_MAX_DOMAINS 8
+#define GMP_STEP_MAX_TASKS 8
+#define GMP_STEP_LAYERS 5
+#define GMP_STEP_MAX_ENC_GROUPS 24
+
+enum { GMP_TASK_NFM = 0, GMP_TASK_LP = 1, GMP_TASK_NC = 2, GMP_TASK_GC = 3, GMP_TASK_GP = 4 };
+
+/* per-domain two-layer MLPHead (Linear-ReLU-Dropout-Linear), one row group per domain */
+typedef struct {
+    int32_t k_in, k_hid, k_out, site;
+    int32_t rows[GMP_STEP_MAX_DOMAINS + 1];
+    int64_t off_w0[GMP_STEP_MAX_DOMAINS], off_b0[GMP_STEP_MAX_DOMAINS], off_w3[GMP_STEP_MAX_DOMAINS], off_b3[GMP_STEP_MAX_DOMAINS];
+    int64_t tg_w0[GMP_STEP_MAX_DOMAINS], tg_b0[GMP_STEP_MAX_DOMAINS], tg_w3[GMP_STEP_MAX_DOMAINS], tg_b3[GMP_STEP_MAX_DOMAINS];
+    float *x, *y1, *d1, *y2, *g_out, *g_hid, *g_in;
+} gmp_mlp2;
+
+typedef struct {
+    int32_t kind;                 /* GMP_TASK_* */
+    int32_t row0, row1;           /* this task's rows of the stacked batch */
+    float* g_scale;               /* device float: 1 / pooled size (d total / d loss_sum) */
+    float* loss_sum;              /* device float: receives the task's loss SUM */
+    void* gemm_ws; size_t gemm_ws_bytes;
+    void* loss_ws; size_t loss_ws_bytes;
+    gmp_mlp2 mlp;                 /* NFM, NC, GC, GP */
+    /* gathers: NFM masked rows / NC common rows */
+    const int64_t* idx; int64_t num_idx;
+    float* nfm_target;
+    /* NT-Xent (NC, GC): per-domain pair counts and workspaces; sums land in ntx_sums[d] */
+    int32_t ntx_n[GMP_STEP_MAX_DOMAINS];
+    void* ntx_ws[GMP_STEP_MAX_DOMAINS]; size_t ntx_ws_bytes[GMP_STEP_MAX_DOMAINS];
+    float* ntx_sums;
+    float temperature;
+    /* read-out pooling (GC, GP) */
+    const int32_t* pool_ptr; const int64_t* pool_gid; int32_t pool_B, pool_r0, pool_M;
+    float *pool_mean, *pool_max, *g_mean, *g_max;
+    const float* labels;          /* GP: [B, 12] */
+    /* link prediction */
+    int64_t lp_K; const int64_t* lp_edges; const float* lp_labels;
+    float *lp_feat, *lp_y1, *lp_d1, *lp_y2, *lp_p, *lp_gp, *lp_gy2, *lp_gy1, *lp_gfeat, *lp_ghs, *lp_ghd;
+    int64_t lp_off_w0, lp_off_b0, lp_off_w3, lp_off_b3, lp_tg_w0, lp_tg_b0, lp_tg_w3, lp_tg_b3;
+    int32_t lp_site;
+} gmp_task_desc;
+
+typedef struct {
+    int64_t off_eps, off_w1, off_b1, off_g1, off_be1, off_w2, off_b2, off_g2, off_be2;
+    int64_t tg_eps[GMP_STEP_MAX_TASKS], tg_w1[GMP_STEP_MAX_TASKS], tg_b1[GMP_STEP_MAX_TASKS], tg_g1[GMP_STEP_MAX_TASKS],
+        tg_be1[GMP_STEP_MAX_TASKS], tg_w2[GMP_STEP_MAX_TASKS], tg_b2[GMP_STEP_MAX_TASKS], tg_g2[GMP_STEP_MAX_TASKS],
+        tg_be2[GMP_STEP_MAX_TASKS];
+    float *rm1, *rv1, *rm2, *rv2;                 /* BatchNorm running statistics */
+    float *a, *z1, *r1, *z2, *m1, *s1, *m2, *s2;  /* saved activations / batch statistics */
+} gmp_layer_desc;
+
+typedef struct {
+    /* sizes of this step */
+    int32_t N, E, S, max_seg, num_tiles, num_tasks, num_domains, dpad, training, hidden;
+    float dropout_p;
+    uint64_t seed;
+    /* uploaded index arrays */
+    const int32_t *seg_ptr, *seg_dom, *src_row, *tiles;
+    const int64_t *edge_index, *rowmask;
+    int32_t task_row[GMP_STEP_MAX_TASKS + 1];   /* host: first stacked row of each task */
+    int32_t task_seg[GMP_STEP_MAX_TASKS + 1];   /* host: first segment of each task */
+    /* graph structure scratch */
+    int32_t* csr[6]; int32_t* csr_status; void* csr_ws; size_t csr_ws_bytes;
+    int32_t* lp_csr[6]; int32_t* lp_csr_status; void* lp_csr_ws; size_t lp_csr_ws_bytes;
+    /* parameters and per-task gradients */
+    float* flat; int64_t P; float* task_grads;
+    /* encoders */
+    const float* x_all; int64_t x_rows;
+    int64_t enc_off_w[GMP_STEP_MAX_DOMAINS], enc_off_b[GMP_STEP_MAX_DOMAINS]; int32_t enc_d_in[GMP_STEP_MAX_DOMAINS];
+    int64_t enc_off_gamma0, enc_off_beta0;
+    float *enc_rm, *enc_rv, *enc_mean, *enc_rstd, *z0;
+    int32_t enc_groups; int32_t enc_gseg[GMP_STEP_MAX_ENC_GROUPS + 1];
+    int64_t enc_tg_w[GMP_STEP_MAX_ENC_GROUPS], enc_tg_b[GMP_STEP_MAX_ENC_GROUPS], enc_tg_gamma[GMP_STEP_MAX_ENC_GROUPS],
+        enc_tg_beta[GMP_STEP_MAX_ENC_GROUPS];
+    int64_t off_mask_token, tg_mask_token; int32_t nfm_task;      /* nfm_task = -1 when the scheme has no NFM */
+    /* backbone */
+    float* h[GMP_STEP_LAYERS + 1];
+    gmp_layer_desc layer[GMP_STEP_LAYERS];
+    float *gA, *gB, *gW, *gW2, *rowdot;
+    void* bn_ws; size_t bn_ws_bytes;
+    void* gemm_ws; size_t gemm_ws_bytes;
+    void* loss_ws; size_t loss_ws_bytes;
+    gmp_task_desc task[GMP_STEP_MAX_TASKS];
+} gmp_step_desc;
+
+size_t gmp_step_desc_size(void);
+/* main: stream of the stacked pass; task_streams[t]: one stream per task head (may all equal main);
+ * aux: stream for the CSR builds (may equal main). */
+int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* desc, gmp_stream_t main, const gmp_stream_t* task_streams,
+                              gmp_stream_t aux);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNMP_STEP_H */

@@ -159,3 +159,22 @@ def test_engine_step_is_deterministic():
     eng.step_count -= 1
     eng.step(inp, gen, art=art, order=list(tasks))
     assert torch.equal(first, eng.flat), "two runs of the same step differ bitwise"
+
+
+def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence():
+    """csrc/step.hip transcribes engine._forward/_task_head/_backbone_backward: same kernels, same order, same buffers."""
+    outs = []
+    for native in (False, True):
+        _, hm, eng, host, inp, gen, tasks, _ = build("s4", 71)
+        eng.native, eng.dropout_p = native, 0.2
+        g = torch.Generator().manual_seed(5)
+        for _ in range(3):
+            eng.step(inp, g, order=list(tasks))
+        torch.cuda.synchronize()
+        outs.append((eng.flat.clone(), eng.task_grads.clone(), eng.loss_sums.clone(),
+                     {k: v.clone() for k, v in hm.state_dict().items() if "running_" in k}))
+    assert torch.equal(outs[0][0], outs[1][0]), "parameters differ"
+    assert torch.equal(outs[0][1], outs[1][1]), "per-task gradients differ"
+    assert torch.equal(outs[0][2], outs[1][2]), "losses differ"
+    for k in outs[0][3]:
+        assert torch.equal(outs[0][3][k], outs[1][3][k]), k
