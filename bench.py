@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from gnn_pretraining_amd import dist as D, ops, synthetic as S  # noqa: E402
-from gnn_pretraining_amd.engine import StepEngine, StepInputs  # noqa: E402
+from gnn_pretraining_amd.engine import StepEngine, StepInputs, StepPrefetcher  # noqa: E402
 from gnn_pretraining_amd.graph import Batch  # noqa: E402
 from gnn_pretraining_amd.models import PretrainableGNN  # noqa: E402
 from gnn_pretraining_amd.pretrain import pretrain as PT  # noqa: E402
@@ -71,9 +71,9 @@ def make_pool(seed: int, device, dpad: int):
 def run_steps(engine, temperature, pool, gen, n, start=0):
     """The body of run_training (reference pretrain.py:113-155): draw artefacts, 5 task losses, per-task
     gradients, PCGrad, clip, AdamW, scheduler step -- one engine.step per optimisation step."""
-    for i in range(n):
+    for inp, prepared in StepPrefetcher(engine, (pool[(start + i) % len(pool)] for i in range(n)), gen):
         engine.temperature = temperature()
-        engine.step(pool[(start + i) % len(pool)], gen)
+        engine.step(inp, gen, prepared=prepared)
         temperature.step()
 
 

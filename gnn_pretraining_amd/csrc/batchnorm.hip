@@ -170,13 +170,23 @@ __global__ __launch_bounds__(THREADS) void bn_running_kernel(BnArgs a) {
     const float m = a.cfg.momentum;
     if (!a.seg_group) {                  // one parameter set: keep the running pair in registers, loads stay independent
         float rm = a.running_mean[c], rv = a.running_var[c];
-        for (int s = 0; s < a.S; ++s) {
-            const int n = a.seg_ptr[s + 1] - a.seg_ptr[s];
-            if (n <= 0) continue;
-            const float mean = a.save_mean[(int64_t)s * a.C + c], rstd = a.save_rstd[(int64_t)s * a.C + c];
-            const float var = 1.f / (rstd * rstd) - a.cfg.eps;
-            rm = (1.f - m) * rm + m * mean;
-            rv = (1.f - m) * rv + m * (n > 1 ? var * ((float)n / (float)(n - 1)) : var);
+        for (int s0 = 0; s0 < a.S; s0 += 8) {           // 8 segments' statistics in flight, folded in order
+            float mean[8], rstd[8];
+            int n[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u;
+                n[u] = s < a.S ? a.seg_ptr[s + 1] - a.seg_ptr[s] : 0;
+                mean[u] = n[u] > 0 ? a.save_mean[(int64_t)s * a.C + c] : 0.f;
+                rstd[u] = n[u] > 0 ? a.save_rstd[(int64_t)s * a.C + c] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (n[u] <= 0) continue;
+                const float var = 1.f / (rstd[u] * rstd[u]) - a.cfg.eps;
+                rm = (1.f - m) * rm + m * mean[u];
+                rv = (1.f - m) * rv + m * (n[u] > 1 ? var * ((float)n[u] / (float)(n[u] - 1)) : var);
+            }
         }
         a.running_mean[c] = rm;
         a.running_var[c] = rv;

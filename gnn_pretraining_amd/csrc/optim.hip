@@ -33,6 +33,7 @@ struct MtArgs {
     int* flags;                // [K]
     float* steps;              // [K]
     int* metrics;              // [2] conflicts, projections
+    int* block_metrics;        // [2 * solve blocks]
     int order[MAXT];           // shuffled task order
     int n_order;               // tasks taking part in PCGrad
     int last_task;             // last task in dict order (keeps its raw .grad where PCGrad emits nothing)
@@ -105,50 +106,75 @@ __global__ __launch_bounds__(64) void gram_finish_kernel(MtArgs a) {
     a.gram[((int64_t)k * MAXT + y) * MAXT + x] = s;
 }
 
-__global__ __launch_bounds__(TB) void solve_kernel(MtArgs a) {
-    __shared__ int s_conf[TB], s_proj[TB];
+__global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
+    __shared__ int s_conf[64], s_proj[64];
     int conf = 0, proj = 0;
-    for (int k = threadIdx.x; k < a.K; k += TB) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k < a.K) {
         const unsigned char* has = a.has + k * MAXT;
         const double* G = a.gram + (int64_t)k * MAXT * MAXT;
-        float w[MAXT];
-        for (int t = 0; t < MAXT; ++t) w[t] = 0.f;
         int flag = 0;
-        const int first = a.order[0];
-        if (has[first]) {
-            double alpha[MAXT][MAXT];
-            for (int i = 0; i < a.T; ++i)
-                for (int j = 0; j < a.T; ++j) alpha[i][j] = i == j ? 1.0 : 0.0;
-            for (int i = 0; i < a.n_order; ++i) {
-                const int ti = a.order[i];
-                if (!has[ti]) continue;
+        float wout[MAXT];                      // indexed by ORDER POSITION (static after unrolling), scattered at the end
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) wout[i] = 0.f;
+        // everything below works in order space: position i <-> task a.order[i]; arrays are indexed only by unrolled
+        // loop counters, so they live in registers (task-indexed arrays would be runtime-indexed -> scratch)
+        bool hp[MAXT];
+        int nh = 0;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            hp[i] = i < a.n_order && has[a.order[i]];
+            nh += hp[i];
+        }
+        if (hp[0]) {
+            double Gp[MAXT][MAXT];
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+                for (int j = 0; j < MAXT; ++j) Gp[i][j] = (hp[i] && hp[j]) ? G[a.order[i] * MAXT + a.order[j]] : 0.0;
+            double alpha[MAXT][MAXT];          // g_i' = sum_j alpha[i][j] g_j   (positions)
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+                for (int j = 0; j < MAXT; ++j) alpha[i][j] = i == j ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 1; i < MAXT; ++i) {
+                if (!hp[i]) continue;
+#pragma unroll
                 for (int j = 0; j < i; ++j) {
-                    const int tj = a.order[j];
-                    if (!has[tj]) continue;
-                    double ni = 0.0;          // only holder x holder entries of G are ever written
-                    for (int p = 0; p < a.T; ++p)
-                        for (int q = 0; q < a.T; ++q)
-                            if (has[p] && has[q]) ni += alpha[ti][p] * alpha[ti][q] * G[p * MAXT + q];
-                    const double nj = G[tj * MAXT + tj];
-                    if (ni <= 0.0 || nj <= 0.0) continue;          // reference: norm() == 0 -> skip the pair
+                    if (!hp[j]) continue;
+                    double ni = 0.0, dot = 0.0;
+#pragma unroll
+                    for (int p = 0; p <= i; ++p) {          // alpha[i][p] is zero beyond p = i
+                        double row = 0.0;
+#pragma unroll
+                        for (int q = 0; q <= i; ++q) row += alpha[i][q] * Gp[p][q];
+                        ni += alpha[i][p] * row;
+                        dot += alpha[i][p] * Gp[p][j];
+                    }
+                    const double nj = Gp[j][j];
+                    if (ni <= 0.0 || nj <= 0.0) continue;   // reference: norm() == 0 -> skip the pair
                     ++proj;
-                    double dot = 0.0;
-                    for (int p = 0; p < a.T; ++p)
-                        if (has[p]) dot += alpha[ti][p] * G[p * MAXT + tj];
                     if (dot < 0.0) {
                         ++conf;
-                        alpha[ti][tj] -= dot / nj;                 // project off task j's ORIGINAL gradient
+                        alpha[i][j] -= dot / nj;            // project off task j's ORIGINAL gradient
                     }
                 }
             }
-            int nh = 0;
-            for (int i = 0; i < a.n_order; ++i) nh += has[a.order[i]] ? 1 : 0;
-            for (int i = 0; i < a.n_order; ++i) {
-                const int ti = a.order[i];
-                if (!has[ti]) continue;
-                for (int b = 0; b < a.T; ++b) w[b] += (float)(alpha[ti][b] / nh);
-            }
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i)
+                if (hp[i]) {
+#pragma unroll
+                    for (int b = 0; b < MAXT; ++b) wout[b] += (float)(alpha[i][b] / nh);
+                }
             flag = 1;
+        }
+        float* w = a.weights + k * MAXT;
+        for (int t = 0; t < MAXT; ++t) w[t] = 0.f;
+        if (flag) {
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i)
+                if (i < a.n_order) w[a.order[i]] = wout[i];
         } else if (a.last_task >= 0 && has[a.last_task]) {
             w[a.last_task] = 1.f;      // untouched by _set_gradients: keeps the last backward's .grad
             flag = 1;
@@ -157,23 +183,22 @@ __global__ __launch_bounds__(TB) void solve_kernel(MtArgs a) {
             w[a.extra_task] += 1.f;    // domain_adv_loss.backward() accumulates on top (pretrain.py:149-150)
             flag = 1;
         }
-        for (int t = 0; t < MAXT; ++t) a.weights[k * MAXT + t] = w[t];
         a.flags[k] = flag;
         if (a.steps) a.steps[k] += (float)flag;     // torch.optim keeps a per-parameter step that only advances with a gradient
     }
     s_conf[threadIdx.x] = conf;
     s_proj[threadIdx.x] = proj;
     __syncthreads();
-    for (int d = TB / 2; d > 0; d >>= 1) {
+    for (int d = 32; d > 0; d >>= 1) {
         if (threadIdx.x < d) {
             s_conf[threadIdx.x] += s_conf[threadIdx.x + d];
             s_proj[threadIdx.x] += s_proj[threadIdx.x + d];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        a.metrics[0] = s_conf[0];
-        a.metrics[1] = s_proj[0];
+    if (threadIdx.x == 0) {            // per-block counts; summed (fixed order) by norm_kernel
+        a.block_metrics[2 * blockIdx.x] = s_conf[0];
+        a.block_metrics[2 * blockIdx.x + 1] = s_proj[0];
     }
 }
 
@@ -214,7 +239,16 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
         if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.normsq[0] = (float)sh[0];
+    if (threadIdx.x == 0) {
+        a.normsq[0] = (float)sh[0];
+        int c = 0, pr = 0;
+        for (int b = 0; b < (a.K + 63) / 64; ++b) {
+            c += a.block_metrics[2 * b];
+            pr += a.block_metrics[2 * b + 1];
+        }
+        a.metrics[0] = c;
+        a.metrics[1] = pr;
+    }
 }
 
 __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
@@ -245,7 +279,8 @@ __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
 
 extern "C" size_t gmp_mt_workspace_bytes(int num_tensors) {
     const size_t K = num_tensors > 0 ? num_tensors : 0;
-    return K * MAXT * MAXT * sizeof(double) * (1 + GCH) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) + 1024;
+    return K * MAXT * MAXT * sizeof(double) * (1 + GCH) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) +
+           (K / 64 + 2) * 2 * sizeof(int) + 1024;
 }
 
 extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
@@ -271,6 +306,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
     a.gram_part = (double*)w; w += (size_t)num_tensors * GCH * MAXT * MAXT * sizeof(double);
     a.weights = (float*)w; w += (size_t)num_tensors * MAXT * sizeof(float);
     a.partial = (float*)w; w += (size_t)num_tensors * CH * sizeof(float);
+    a.block_metrics = (int*)w;
     a.flags = flags_out; a.steps = steps; a.metrics = metrics_out;
     for (int i = 0; i < n_order; ++i) {
         if (order_host[i] < 0 || order_host[i] >= num_tasks) return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: order[%d]=%d", i, order_host[i]);
@@ -284,7 +320,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
         hipLaunchKernelGGL(gram_kernel, dim3(num_tensors, GCH), dim3(TB), 0, st, a);
         hipLaunchKernelGGL(gram_finish_kernel, dim3(num_tensors), dim3(64), 0, st, a);
     }
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL(solve_kernel, dim3((num_tensors + 63) / 64), dim3(64), 0, st, a);
     hipLaunchKernelGGL(combine_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
     hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
     if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);

@@ -570,18 +570,27 @@ class StepEngine:
         return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site)
 
     # ------------------------------------------------------------------ one step
+    def prepare(self, inp: StepInputs, gen: torch.Generator):
+        """Host half of a step (all RNG draws + the segment layout); may run on another thread ahead of time."""
+        art = self.draw(inp, gen)
+        return art, self.plan(inp, art)
+
     def step(self, inp: StepInputs, gen: torch.Generator, art: Optional[Dict[str, object]] = None,
-             order: Optional[List[str]] = None, apply_update: bool = True) -> None:
+             order: Optional[List[str]] = None, apply_update: bool = True, prepared=None) -> None:
         """Forward, backward, PCGrad, clip, AdamW for one step.  Nothing is read back: losses stay in
         self.loss_sums / self.plan_sizes until someone asks (losses())."""
         import time as _t
         self._use_stream()
         t0 = _t.perf_counter()
-        if art is None:
-            art = self.draw(inp, gen)
-        t1 = _t.perf_counter()
-        p = self.plan(inp, art)
-        t2 = _t.perf_counter()
+        if prepared is not None:
+            art, p = prepared
+            t1 = t2 = _t.perf_counter()
+        else:
+            if art is None:
+                art = self.draw(inp, gen)
+            t1 = _t.perf_counter()
+            p = self.plan(inp, art)
+            t2 = _t.perf_counter()
         self._upload(p, inp, art)
         t3 = _t.perf_counter()
         if self.native:
@@ -1197,3 +1206,35 @@ class StepEngine:
         main = torch.cuda.current_stream(self.device)
         self._chk(self.lib.gmp_pretrain_step_fwd_bwd(C.byref(d), main.cuda_stream, self._stream_arr, self.aux_stream.cuda_stream),
                   "gmp_pretrain_step_fwd_bwd")
+
+
+class StepPrefetcher:
+    """Runs engine.prepare() for upcoming steps on a background thread.  The device half of a step is one long C call
+    (gmp_pretrain_step_fwd_bwd) that releases the GIL, so index drawing for step t+1 overlaps the launches of step t.
+    The RNG stream is unchanged: only this thread draws, in step order."""
+
+    def __init__(self, engine: StepEngine, inputs, gen: torch.Generator, depth: int = 3) -> None:
+        import queue
+        import threading
+        self.q: "queue.Queue" = queue.Queue(maxsize=depth)
+        self._err = None
+
+        def work() -> None:
+            try:
+                for inp in inputs:
+                    self.q.put((inp, engine.prepare(inp, gen)))
+            except BaseException as e:           # surfaced on the consumer side
+                self._err = e
+            self.q.put(None)
+
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                if self._err is not None:
+                    raise self._err
+                return
+            yield item
