@@ -14,7 +14,7 @@ namespace {
     } while (0)
 
 constexpr int H = 256;
-constexpr int NEV = 2 + GMP_STEP_MAX_TASKS + 2;
+constexpr int NEV = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 2;
 
 hipEvent_t* events() {   // one process drives one engine: a small static pool of timing-free events
     static hipEvent_t ev[NEV];
@@ -264,24 +264,44 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     }
     (void)hipStreamWaitEvent(main, ev[2], 0);
 
-    // ---- stacked backbone backward: per-task parameter gradients from ONE pass
-    float *gcur = d.gA, *gu = d.gB, *ga = d.h[GMP_STEP_LAYERS];
+    // ---- stacked backbone backward: per-task parameter gradients from ONE pass.
+    // The input-gradient chain (BN bwd -> dgrad GEMM -> BN bwd -> dgrad GEMM -> aggregation bwd) is the critical path;
+    // the weight-gradient GEMMs only feed task_grads, so they run beside it on the aux stream.  gB/gB2 and gW2/gW3
+    // alternate per layer so a layer's weight-gradient GEMM can still read its operand while the next layer writes.
+    hipEvent_t* evl = ev + 4 + GMP_STEP_MAX_TASKS;       // per layer: [0] g_u ready, [1] dW2 done, [2] g_z1 ready, [3] dW1 done
+    float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
+        float* gu = (l & 1) ? d.gB2 : d.gB;
+        float* gz1 = (l & 1) ? d.gW3 : d.gW2;
+        hipEvent_t* e = evl + 4 * l;
+        if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 1], 0);   // dW2 of layer l+2 has read this gu copy
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
                            tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        (void)hipEventRecord(e[0], main);
+        (void)hipStreamWaitEvent(aux, e[0], 0);
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
-                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, main_));
+                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
+        (void)hipEventRecord(e[1], aux);
         GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
+        if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
-                           L.s1, d.gW2, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
-        GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, d.gW2, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
-                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, main_));
-        GMP_TRY(gemm(GMP_GEMM_NN, d.gW2, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
+                           L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        (void)hipEventRecord(e[2], main);
+        (void)hipStreamWaitEvent(aux, e[2], 0);
+        GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
+                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
+        (void)hipEventRecord(e[3], aux);
+        GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
+    }
+    float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
+    for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
+        (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
+        (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
     }
     // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
     if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {

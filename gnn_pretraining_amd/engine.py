@@ -226,6 +226,7 @@ class StepEngine:
         self.gA, self.gB = f(R, H), f(R, H)                  # ping-pong [R,256] gradients
         self.gW = f(R, 2 * H)                                # [R,512] gradients
         self.gW2 = f(R, 2 * H)
+        self.gB2, self.gW3 = f(R, H), f(R, 2 * H)
         self.rowdot = f(R)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs
         # the task heads are independent of each other: each runs on its own stream with its own scratch
@@ -1075,6 +1076,7 @@ class StepEngine:
             Ld.a, Ld.z1, Ld.r1, Ld.z2 = ptr(self.a[l]), ptr(self.z1[l]), ptr(self.r1[l]), ptr(self.z2[l])
             Ld.m1, Ld.s1, Ld.m2, Ld.s2 = ptr(self.stat["m1"][l]), ptr(self.stat["s1"][l]), ptr(self.stat["m2"][l]), ptr(self.stat["s2"][l])
         d.gA, d.gB, d.gW, d.gW2, d.rowdot = ptr(self.gA), ptr(self.gB), ptr(self.gW), ptr(self.gW2), ptr(self.rowdot)
+        d.gB2, d.gW3 = ptr(self.gB2), ptr(self.gW3)
         d.bn_ws, d.bn_ws_bytes = ptr(self.bn_ws), self.bn_ws.numel()
         d.gemm_ws, d.gemm_ws_bytes = ptr(self.gemm_ws), self.gemm_ws.numel()
         d.loss_ws, d.loss_ws_bytes = ptr(self.task_loss_ws[0]), self.task_loss_ws[0].numel()

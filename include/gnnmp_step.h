@@ -99,6 +99,8 @@ typedef struct {
     float* h[GMP_STEP_LAYERS + 1];
     gmp_layer_desc layer[GMP_STEP_LAYERS];
     float *gA, *gB, *gW, *gW2, *rowdot;
+    float *gB2, *gW3;             /* second copies of gB / gW2: weight-gradient GEMMs of layer l read them on the aux stream
+                                     while layer l-1 already writes the other copy */
     void* bn_ws; size_t bn_ws_bytes;
     void* gemm_ws; size_t gemm_ws_bytes;
     void* loss_ws; size_t loss_ws_bytes;
