@@ -3,7 +3,7 @@ gmp_step_desc_size() is compared against ctypes.sizeof at load time)."""
 import ctypes as C
 
 MAXD, MAXT, LAYERS, MAXG = 8, 8, 5, 24
-TASK_KIND = {"node_feat_mask": 0, "link_pred": 1, "node_contrast": 2, "graph_contrast": 3, "graph_prop": 4}
+TASK_KIND = {"node_feat_mask": 0, "link_pred": 1, "node_contrast": 2, "graph_contrast": 3, "graph_prop": 4, "domain_adv": 5}
 i32, i64, u64, f32, p, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p, C.c_size_t
 
 
@@ -25,7 +25,8 @@ class TaskDesc(C.Structure):
                 ("lp_feat", p), ("lp_y1", p), ("lp_d1", p), ("lp_y2", p), ("lp_p", p), ("lp_gp", p), ("lp_gy2", p), ("lp_gy1", p),
                 ("lp_gfeat", p), ("lp_ghs", p), ("lp_ghd", p),
                 ("lp_off_w0", i64), ("lp_off_b0", i64), ("lp_off_w3", i64), ("lp_off_b3", i64),
-                ("lp_tg_w0", i64), ("lp_tg_b0", i64), ("lp_tg_w3", i64), ("lp_tg_b3", i64), ("lp_site", i32)]
+                ("lp_tg_w0", i64), ("lp_tg_b0", i64), ("lp_tg_w3", i64), ("lp_tg_b3", i64), ("lp_site", i32),
+                ("da_labels", p), ("da_classes", i32), ("da_hidden", i32), ("da_lambda", f32), ("da_dropout", f32)]
 
 
 class LayerDesc(C.Structure):

@@ -186,6 +186,32 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(mlp2_bwd(d, t, d1, st));
             return gmp_row_gather(m.g_in, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st);
         }
+        case GMP_TASK_DA: {
+            const int B = t.pool_B, Hd = t.da_hidden, Cc = t.da_classes;
+            const float *w0 = d.flat + t.lp_off_w0, *b0 = d.flat + t.lp_off_b0, *w3 = d.flat + t.lp_off_w3, *b3 = d.flat + t.lp_off_b3;
+            const float pdrop = d.training ? t.da_dropout : 0.f;
+            GMP_TRY(gmp_segment_sum(hL, t.pool_ptr, nullptr, m.x, B, H, 1, 0, st));
+            GMP_TRY(gemm(GMP_GEMM_NT, m.x, w0, b0, m.y1, B, Hd, H, H, H, Hd, true, st));
+            float* dd1 = m.y1;
+            if (pdrop > 0.f) {
+                GMP_TRY(gmp_dropout_fwd(m.y1, m.d1, (int64_t)B * Hd, pdrop, d.seed, t.lp_site, st));
+                dd1 = m.d1;
+            }
+            GMP_TRY(gemm(GMP_GEMM_NT, dd1, w3, b3, m.y2, B, Cc, Hd, Hd, Hd, Cc, false, st));
+            GMP_TRY(gmp_cross_entropy_sum_fwd(m.y2, t.da_labels, B, Cc, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gmp_cross_entropy_sum_bwd(m.y2, t.da_labels, B, Cc, t.g_scale, m.g_out, st));
+            const int32_t one[2] = {0, B};
+            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3}, cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_out, dd1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, Cc, Hd, 0, Cc, Hd, Hd, 1.f, 0, 0,
+                                         nullptr, 0, st));
+            GMP_TRY(gemm(GMP_GEMM_NN, m.g_out, w3, nullptr, m.g_hid, B, Hd, Cc, Cc, Hd, Hd, false, st));
+            GMP_TRY(gmp_relu_dropout_bwd(m.g_hid, m.y1, m.g_hid, (int64_t)B * Hd, pdrop, d.seed, t.lp_site, st));
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_hid, m.x, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, Hd, H, 0, Hd, H, H, 1.f, 0, 0,
+                                         nullptr, 0, st));
+            // gradient reversal: d/d pooled = -lambda * (g_hid W0)
+            GMP_TRY(gmp_gemm_f32(GMP_GEMM_NN, m.g_hid, w0, nullptr, m.g_in, B, H, Hd, Hd, H, H, -t.da_lambda, 0, 0, nullptr, 0, st));
+            return gmp_row_gather(m.g_in, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st);
+        }
         default:
             return gmp::fail(GMP_ERR_ARG, "step: unknown task kind %d", t.kind);
     }

@@ -40,7 +40,8 @@ from .pretrain.tasks import sample_negative_edges
 H = GNN_HIDDEN_DIM
 NT, NN, TN = 0, 1, 2
 MAXT = 8
-SUPPORTED_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop")
+SUPPORTED_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop", "domain_adv")
+DA_HIDDEN, DA_DROPOUT = 128, 0.5          # heads.py:11-12
 
 
 _ARR_CACHE: Dict[Tuple, "C.Array"] = {}
@@ -124,6 +125,8 @@ class StepEngine:
         self.shuffle_rng = shuffle_rng
         self.grad_sync = grad_sync
         self.temperature = 0.5
+        self.da_dropout = DA_DROPOUT
+        self.grl_lambda = 0.0              # gradient-reversal strength of the domain-adversarial task (GRLScheduler)
         self._p_cache, self._tg_cache = {}, {}
         self._stream_handle = torch.cuda.current_stream(self.device).cuda_stream if torch.cuda.is_available() else 0
         self.host_ms = {"draw": 0.0, "plan": 0.0, "upload": 0.0, "launch": 0.0, "steps": 0}   # host time per phase (upload includes ring waits)
@@ -254,6 +257,8 @@ class StepEngine:
             "nc_in": (2 * R, H), "nc_y1": (2 * R, H), "nc_d1": (2 * R, H), "nc_z": (2 * R, 128), "nc_gz": (2 * R, 128), "nc_g1": (2 * R, H), "nc_gin": (2 * R, H),
             "gc_mean": (1024, H), "gc_max": (1024, H), "gc_in": (1024, 2 * H), "gc_y1": (1024, H), "gc_d1": (1024, H), "gc_z": (1024, 128),
             "gc_gz": (1024, 128), "gc_g1": (1024, H), "gc_gin": (1024, 2 * H), "gc_gmean": (1024, H), "gc_gmax": (1024, H),
+            "da_in": (1024, H), "da_y1": (1024, DA_HIDDEN), "da_d1": (1024, DA_HIDDEN), "da_logits": (1024, 8), "da_glogits": (1024, 8),
+            "da_g1": (1024, DA_HIDDEN), "da_gin": (1024, H),
             "gp_in": (1024, H), "gp_y1": (1024, 2 * H), "gp_d1": (1024, 2 * H), "gp_y2": (1024, 16), "gp_g2": (1024, 16), "gp_g1": (1024, 2 * H), "gp_gin": (1024, H),
         }.items()}
         self.lp_y2, self.lp_p, self.lp_lab, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)
@@ -448,7 +453,7 @@ class StepEngine:
             return r0
 
         for ti, t in enumerate(self.tasks):
-            if t in ("node_feat_mask", "link_pred", "graph_prop"):
+            if t in ("node_feat_mask", "link_pred", "graph_prop", "domain_adv"):
                 r0s = []
                 for di, d in enumerate(D):
                     hb, roff = inp.host[d], inp.row_off[d]
@@ -474,17 +479,25 @@ class StepEngine:
                     p.lp_labels, p.lp_K = lab, e.shape[1]
                     sizes[t] = e.shape[1]
                 else:
-                    starts, rows = [], [0]
-                    for d, r0 in zip(D, r0s):
+                    starts, rows, labels = [], [0], []
+                    for di, (d, r0) in enumerate(zip(D, r0s)):
                         ph = inp.host[d].ptr_host
                         starts += [r0 + v for v in ph[:-1]]
                         rows.append(rows[-1] + len(ph) - 1)
+                        labels += [di] * (len(ph) - 1)
                     end = seg_ptr[-1]
                     ptr = np.asarray(starts + [end], dtype=np.int64)
-                    a32["gp_ptr"] = ptr
-                    a64["gp_gid"] = np.repeat(np.arange(len(starts)), np.diff(ptr))
-                    p.gp_rows, p.gp_B, p.gp_r0, p.gp_M = rows, len(starts), task_row[-1], end - task_row[-1]
-                    sizes[t] = rows[-1] * GRAPH_PROPERTY_DIM
+                    if t == "graph_prop":
+                        a32["gp_ptr"] = ptr
+                        a64["gp_gid"] = np.repeat(np.arange(len(starts)), np.diff(ptr))
+                        p.gp_rows, p.gp_B, p.gp_r0, p.gp_M = rows, len(starts), task_row[-1], end - task_row[-1]
+                        sizes[t] = rows[-1] * GRAPH_PROPERTY_DIM
+                    else:                                   # domain_adv: label = index of the graph's domain (tasks.py:333)
+                        a32["da_ptr"] = ptr
+                        a64["da_gid"] = np.repeat(np.arange(len(starts)), np.diff(ptr))
+                        a64["da_labels"] = np.asarray(labels, dtype=np.int64)
+                        p.da_B, p.da_r0, p.da_M = len(starts), task_row[-1], end - task_row[-1]
+                        sizes[t] = len(starts)
             else:
                 idx, rows, ns, starts = [], [0], [], []
                 for di, d in enumerate(D):
@@ -736,16 +749,17 @@ class StepEngine:
                                      self.h[l + 1].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2")
 
     # ---- head helpers ------------------------------------------------------------------------------
-    def _drop(self, src: Tensor, dst: Tensor, numel: int, site: int) -> Tensor:
+    def _drop(self, src: Tensor, dst: Tensor, numel: int, site: int, p: Optional[float] = None) -> Tensor:
         """dropout(src) -> dst (returns the tensor holding the result; p == 0 aliases src)."""
-        if not self.model.training or self.dropout_p <= 0:
+        p = self.dropout_p if p is None else p
+        if not self.model.training or p <= 0:
             return src
-        self._chk(self.lib.gmp_dropout_fwd(src.data_ptr(), dst.data_ptr(), numel, self.dropout_p,
+        self._chk(self.lib.gmp_dropout_fwd(src.data_ptr(), dst.data_ptr(), numel, p,
                                            (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site, self._st()), "dropout")
         return dst
 
-    def _relu_drop_bwd(self, g: Tensor, act: Tensor, out: Tensor, numel: int, site: int) -> None:
-        p = self.dropout_p if self.model.training else 0.0
+    def _relu_drop_bwd(self, g: Tensor, act: Tensor, out: Tensor, numel: int, site: int, p: Optional[float] = None) -> None:
+        p = (self.dropout_p if p is None else p) if self.model.training else 0.0
         self._chk(self.lib.gmp_relu_dropout_bwd(g.data_ptr(), act.data_ptr(), out.data_ptr(), numel, p,
                                                 (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site, self._st()), "relu_dropout_bwd")
 
@@ -897,6 +911,27 @@ class StepEngine:
                 self._mlp2_grouped_bwd(ti, t, hd["gp_in"], rows, H, 2 * H, G, hd["gp_y1"], d1, self.gp_g2, hd["gp_g1"], hd["gp_gin"], 100 + ti)
                 g_rows = gH.data_ptr() + 4 * H * p.gp_r0
                 self._chk(lib.gmp_row_gather(hd["gp_gin"].data_ptr(), p.d64["gp_gid"], p.d32["gp_ptr"], g_rows, p.gp_M, B, H, st), "gp mean bwd")
+            elif t == "domain_adv":
+                # mean read-out -> gradient reversal -> Linear 256->128, ReLU, Dropout(.5), Linear 128->D -> CE(sum)  (heads.py:70-82)
+                B, Cc, lam = p.da_B, len(D), float(self.grl_lambda)
+                pre = "heads.domain_adv.classifier.mlp."
+                w0, b0, w3, b3 = P(pre + "0.weight"), P(pre + "0.bias"), P(pre + "3.weight"), P(pre + "3.bias")
+                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["da_ptr"], None, hd["da_in"].data_ptr(), B, H, 1, 0, st), "da mean")
+                self._gemm(NT, hd["da_in"].data_ptr(), w0, b0, hd["da_y1"].data_ptr(), B, DA_HIDDEN, H, H, H, DA_HIDDEN, relu=True)
+                d1 = self._drop(hd["da_y1"], hd["da_d1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
+                self._gemm(NT, d1.data_ptr(), w3, b3, hd["da_logits"].data_ptr(), B, Cc, DA_HIDDEN, DA_HIDDEN, DA_HIDDEN, Cc)
+                self._chk(lib.gmp_cross_entropy_sum_fwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "da ce")
+                self._chk(lib.gmp_cross_entropy_sum_bwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, gs, hd["da_glogits"].data_ptr(), st), "da ce bwd")
+                one = [0, B]
+                self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_glogits"].data_ptr(), d1.data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "3.weight")]),
+                                                   tg, _i64([TG(ti, pre + "3.bias")]), Cc, DA_HIDDEN, 0, Cc, DA_HIDDEN, DA_HIDDEN, 1.0, 0, 0, None, 0, st), "da dW3")
+                self._gemm(NN, hd["da_glogits"].data_ptr(), w3, None, hd["da_g1"].data_ptr(), B, DA_HIDDEN, Cc, Cc, DA_HIDDEN, DA_HIDDEN)
+                self._relu_drop_bwd(hd["da_g1"], hd["da_y1"], hd["da_g1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
+                self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_g1"].data_ptr(), hd["da_in"].data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "0.weight")]),
+                                                   tg, _i64([TG(ti, pre + "0.bias")]), DA_HIDDEN, H, 0, DA_HIDDEN, H, H, 1.0, 0, 0, None, 0, st), "da dW0")
+                self._chk(lib.gmp_gemm_f32(NN, hd["da_g1"].data_ptr(), w0, None, hd["da_gin"].data_ptr(), B, H, DA_HIDDEN, DA_HIDDEN, H, H, -lam, 0, 0, None, 0, st), "da grl")
+                g_rows = gH.data_ptr() + 4 * H * p.da_r0
+                self._chk(lib.gmp_row_gather(hd["da_gin"].data_ptr(), p.d64["da_gid"], p.d32["da_ptr"], g_rows, p.da_M, B, H, st), "da mean bwd")
 
     def _nt_xent_domains(self, ns: List[int], rows: List[int], z: Tensor, gz: Tensor, gs: int, ls: int, temperature: float, slot0: int) -> None:
         """One NT-Xent problem per domain on rows [rows[d], rows[d+1]) = [z1 ; z2]; loss sums land in scal[16+slot],
@@ -1001,15 +1036,17 @@ class StepEngine:
         if self.grad_sync is not None:
             self._sync_task_grads()
         names = list(self.tasks)
+        main_tasks = [t for t in names if t != "domain_adv"]     # pretrain.py:137-150: PCGrad over the main tasks, then
+        extra = names.index("domain_adv") if "domain_adv" in names else -1   # domain_adv_loss.backward() accumulates on top
         if order is None:
-            order = list(names)
+            order = list(main_tasks)
             if len(order) > 1:
                 (self.shuffle_rng or random).shuffle(order)       # reference: unseeded random.shuffle (gradient_surgery.py:43)
         idx = [names.index(t) for t in order]
         self.last_order = order
         self._chk(self.lib.gmp_mt_pcgrad_clip_adamw(
             self.task_grads.data_ptr(), self.P, self.T, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(),
-            _i32(idx), len(idx), self.T - 1, -1, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            _i32(idx), len(idx), names.index(main_tasks[-1]), extra, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
             self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, self.max_grad_norm,
             self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(), self.mt_ws.data_ptr(),
             self.mt_ws.numel(), int(apply_update), self._st()), "mt_pcgrad_clip_adamw")
@@ -1110,6 +1147,14 @@ class StepEngine:
                 td.ntx_sums = sc + 4 * (16 + (0 if t == "node_contrast" else self.D))
             if t == "graph_contrast":
                 td.pool_mean, td.pool_max, td.g_mean, td.g_max = ptr(hd["gc_mean"]), ptr(hd["gc_max"]), ptr(hd["gc_gmean"]), ptr(hd["gc_gmax"])
+            if t == "domain_adv":
+                m = td.mlp
+                m.x, m.y1, m.d1, m.y2, m.g_out, m.g_hid, m.g_in = (ptr(hd[k]) for k in ("da_in", "da_y1", "da_d1", "da_logits", "da_glogits", "da_g1", "da_gin"))
+                for a, n in (("w0", "mlp.0.weight"), ("b0", "mlp.0.bias"), ("w3", "mlp.3.weight"), ("b3", "mlp.3.bias")):
+                    full = f"heads.domain_adv.classifier.{n}"
+                    setattr(td, "lp_off_" + a, self.off[full])
+                    setattr(td, "lp_tg_" + a, self._TG(ti, full))
+                td.lp_site, td.da_classes, td.da_hidden, td.da_dropout = 100 + ti, len(D), DA_HIDDEN, DA_DROPOUT
             if t == "link_pred":
                 td.lp_labels = ptr(self.lp_lab)
                 for a in ("feat", "y1", "d1", "gy1", "gfeat", "ghs", "ghd"):
@@ -1176,6 +1221,9 @@ class StepEngine:
             if t == "graph_prop":
                 td.pool_ptr, td.pool_gid, td.pool_B, td.pool_r0, td.pool_M = p.d32["gp_ptr"], p.d64["gp_gid"], p.gp_B, p.gp_r0, p.gp_M
                 td.labels = inp.graph_props.data_ptr()
+            if t == "domain_adv":
+                td.pool_ptr, td.pool_gid, td.pool_B, td.pool_r0, td.pool_M = p.d32["da_ptr"], p.d64["da_gid"], p.da_B, p.da_r0, p.da_M
+                td.da_labels, td.da_lambda, td.da_dropout = p.d64["da_labels"], float(self.grl_lambda), float(self.da_dropout)
             if t == "link_pred":
                 td.lp_K, td.lp_edges = p.lp_K, p.d64["lp_edges"]
         return d

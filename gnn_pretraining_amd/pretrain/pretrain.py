@@ -116,7 +116,7 @@ def run_training_engine(state: StepState, engine, steps: int, generator: torch.G
     for _ in range(steps):
         global_step[0] += 1
         inp = StepInputs(synthetic.pretrain_step_batches(generator, state.cfg.pretrain_domains), device, engine.dpad)
-        engine.temperature = state.temperature()
+        engine.temperature, engine.grl_lambda = state.temperature(), state.grl()
         engine.step(inp, generator)
         state.grl.step()
         state.temperature.step()
@@ -182,7 +182,7 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: int = 4
     logger = JsonlLogger(log_path)
     engine = None
     from ..engine import SUPPORTED_TASKS, StepEngine
-    if all(t in SUPPORTED_TASKS for t in cfg.active_tasks):       # s5's domain_adv runs on the module path
+    if all(t in SUPPORTED_TASKS for t in cfg.active_tasks):
         engine = StepEngine(model, cfg.active_tasks, cfg.pretrain_domains, dev, seed=cfg.seed)
     best, stale, global_step = float("inf"), 0, [0]
     path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"

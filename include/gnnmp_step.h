@@ -24,7 +24,7 @@ extern "C" {
 #define GMP_STEP_LAYERS 5
 #define GMP_STEP_MAX_ENC_GROUPS 24
 
-enum { GMP_TASK_NFM = 0, GMP_TASK_LP = 1, GMP_TASK_NC = 2, GMP_TASK_GC = 3, GMP_TASK_GP = 4 };
+enum { GMP_TASK_NFM = 0, GMP_TASK_LP = 1, GMP_TASK_NC = 2, GMP_TASK_GC = 3, GMP_TASK_GP = 4, GMP_TASK_DA = 5 };
 
 /* per-domain two-layer MLPHead (Linear-ReLU-Dropout-Linear), one row group per domain */
 typedef struct {
@@ -58,8 +58,14 @@ typedef struct {
     /* link prediction */
     int64_t lp_K; const int64_t* lp_edges; const float* lp_labels;
     float *lp_feat, *lp_y1, *lp_d1, *lp_y2, *lp_p, *lp_gp, *lp_gy2, *lp_gy1, *lp_gfeat, *lp_ghs, *lp_ghd;
+    /* offsets of a head shared by all domains: the LP scorer, and the domain classifier of GMP_TASK_DA */
     int64_t lp_off_w0, lp_off_b0, lp_off_w3, lp_off_b3, lp_tg_w0, lp_tg_b0, lp_tg_w3, lp_tg_b3;
     int32_t lp_site;
+    /* domain-adversarial task (scheme s5; tasks.py:315-343, heads.py:16-32,70-82): mean read-out -> gradient reversal
+     * (backward scaled by -da_lambda) -> Linear 256->128, ReLU, Dropout(da_dropout), Linear 128->da_classes -> CE(sum)
+     * against da_labels (the graph's domain index).  Buffers: mlp.x = pooled, mlp.y1/d1 hidden, mlp.y2 logits,
+     * mlp.g_out = d loss / d logits, mlp.g_hid, mlp.g_in = d loss / d pooled. */
+    const int64_t* da_labels; int32_t da_classes, da_hidden; float da_lambda, da_dropout;
 } gmp_task_desc;
 
 typedef struct {

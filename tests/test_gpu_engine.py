@@ -36,7 +36,7 @@ def build(scheme, seed, rng_mode="reference"):
     set_dropout(om, 0.0)
     om.train(); hm.train()
     eng = StepEngine(hm, tasks, domains, DEV, seed=seed, rng_mode=rng_mode)
-    eng.dropout_p = 0.0
+    eng.dropout_p = eng.da_dropout = 0.0
     host = S.pretrain_step_batches(gen, domains)
     inp = StepInputs(host, DEV, eng.dpad)
     return om, hm, eng, host, inp, gen, tasks, domains
@@ -78,17 +78,18 @@ def oracle_artefacts(art, host):
 
 
 @pytest.mark.parametrize("scheme,seed,rng_mode", [("s4", 41, "reference"), ("b2", 42, "reference"), ("s2", 43, "reference"),
-                                                  ("b4", 44, "reference"), ("s4", 45, "vectorized"), ("s3", 46, "vectorized")])
+                                                  ("b4", 44, "reference"), ("s4", 45, "vectorized"), ("s3", 46, "vectorized"),
+                                                  ("s5", 47, "reference")])
 def test_engine_losses_task_gradients_and_running_stats(scheme, seed, rng_mode):
     om, hm, eng, host, inp, gen, tasks, domains = build(scheme, seed, rng_mode)
     art = eng.draw(inp, gen)
-    eng.temperature = 0.37
-    eng.step(inp, gen, art=art, order=list(tasks), apply_update=False)
+    eng.temperature, eng.grl_lambda = 0.37, 0.007
+    eng.step(inp, gen, art=art, order=[t for t in tasks if t != "domain_adv"], apply_update=False)
     got_losses = eng.losses()
     o_batches = {d: to_oracle(b) for d, b in host.items()}
     temp = OTr.TemperatureScheduler(100)
     temp.__call__ = lambda: 0.37
-    otasks = OTk.instantiate_tasks(om, tasks, None, lambda: 0.37)
+    otasks = OTk.instantiate_tasks(om, tasks, lambda: 0.007, lambda: 0.37)
     o_art = oracle_artefacts(art, host)
     names = dict(om.named_parameters())
     for name in tasks:
@@ -161,15 +162,16 @@ def test_engine_step_is_deterministic():
     assert torch.equal(first, eng.flat), "two runs of the same step differ bitwise"
 
 
-def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence():
+@pytest.mark.parametrize("scheme", ["s4", "s5"])
+def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence(scheme):
     """csrc/step.hip transcribes engine._forward/_task_head/_backbone_backward: same kernels, same order, same buffers."""
     outs = []
     for native in (False, True):
-        _, hm, eng, host, inp, gen, tasks, _ = build("s4", 71)
-        eng.native, eng.dropout_p = native, 0.2
+        _, hm, eng, host, inp, gen, tasks, _ = build(scheme, 71)
+        eng.native, eng.dropout_p, eng.da_dropout, eng.grl_lambda = native, 0.2, 0.5, 0.004
         g = torch.Generator().manual_seed(5)
         for _ in range(3):
-            eng.step(inp, g, order=list(tasks))
+            eng.step(inp, g, order=[t for t in tasks if t != "domain_adv"])
         torch.cuda.synchronize()
         outs.append((eng.flat.clone(), eng.task_grads.clone(), eng.loss_sums.clone(),
                      {k: v.clone() for k, v in hm.state_dict().items() if "running_" in k}))
@@ -178,3 +180,34 @@ def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence():
     assert torch.equal(outs[0][2], outs[1][2]), "losses differ"
     for k in outs[0][3]:
         assert torch.equal(outs[0][3][k], outs[1][3][k]), k
+
+
+def test_engine_s5_step_with_domain_adversarial_term():
+    """Scheme s5: PCGrad over the five main tasks, then the domain-adversarial gradient (through the gradient-reversal
+    layer, lambda from the GRL scheduler) accumulates on top (pretrain.py:137-150)."""
+    om, hm, eng, host, inp, gen, tasks, domains = build("s5", 81)
+    before = {k: v.clone() for k, v in om.state_dict().items()}
+    art = eng.draw(inp, gen)
+    order = ["graph_prop", "link_pred", "node_contrast", "node_feat_mask", "graph_contrast"]
+    temp, grl = OTr.TemperatureScheduler(1000), OTr.GRLScheduler(10, 10)
+    grl.current_step = 70                       # lambda = 0.00987 (golden value of the reference scheduler)
+    otasks = OTk.instantiate_tasks(om, tasks, grl, temp)
+    oopt, obal = OTr.make_optimizer(om, tasks), OTr.AdaptiveLossBalancer()
+    for g in oopt.param_groups:
+        g["lr"] *= 1000
+    eng.lr.mul_(1000)
+    eng.temperature, eng.grl_lambda = temp(), grl()
+    o_batches = {d: to_oracle(b) for d, b in host.items()}
+    lo, _, _, _ = OTr.train_step(om, otasks, oopt, obal, grl, temp, o_batches, gen, artifacts=oracle_artefacts(art, host), order=order)
+    eng.step(inp, gen, art=art, order=order)
+    got = eng.losses()
+    for n in tasks:
+        assert abs(got[n] - lo[n].item()) <= 1e-4 * abs(lo[n].item()), n
+    after_o, after_h = om.state_dict(), hm.state_dict()
+    moved_o = {k for k in before if before[k].dtype.is_floating_point and "running_" not in k and not torch.equal(before[k], after_o[k])}
+    moved_h = {k for k in before if before[k].dtype.is_floating_point and "running_" not in k and not torch.equal(before[k], after_h[k].cpu())}
+    assert moved_h == moved_o, sorted(moved_h ^ moved_o)[:10]
+    assert "heads.domain_adv.classifier.mlp.0.weight" in moved_o
+    num = sum(((after_h[k].cpu() - after_o[k]).double() ** 2).sum().item() for k in moved_o)
+    den = sum(((after_o[k] - before[k]).double() ** 2).sum().item() for k in moved_o)
+    assert (num / den) ** 0.5 <= 2e-2, f"relative update error {(num / den) ** 0.5:.3e}"
