@@ -1,27 +1,78 @@
-"""Fine-tuning loop on libgnnmp with the structure of src/finetune/finetune.py: FinetuneConfig, process_batch per task
-type, one optimiser step per batch (AdamW over FinetuneGNN.param_groups), best-validation checkpoint.  Data are
-synthetic stand-ins of the reference's shapes (Cora-like single graph for *_NC, ENZYMES-shaped batches for graph
-classification); sklearn metrics and wandb are out of scope.  Link-prediction fine-tuning needs the
-hard-negative miner and is not part of this round."""
+"""Fine-tuning loop on libgnnmp with the structure of src/finetune/finetune.py: FinetuneConfig, the hard-negative
+miner, process_batch per task type, one AdamW step per batch over FinetuneGNN.param_groups, best-validation checkpoint,
+test metrics from the best checkpoint.  Data come from the loaders of gnn_pretraining_amd/data (processed datasets in
+data/processed; synthetic stand-ins are generated when none were exported).  wandb is replaced by a JSONL logger with the
+same metric keys.  Build-only flags: --epochs, --device, --data-root, --data-scale, --log."""
 from __future__ import annotations
 
 import argparse
+import json
 import time
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
+from torch import Tensor
 
-from .. import operators as O, synthetic as S
-from ..constants import DOMAIN_DIMENSIONS, NUM_CLASSES, TASK_TYPES
-from ..graph import Batch
+from .. import operators as O, ops
+from ..constants import NUM_CLASSES, TASK_TYPES
 from ..models.finetune_model import FinetuneGNN, create_finetune_model
+from .metrics import compute_batch_metrics, compute_test_metrics, compute_training_metrics, compute_validation_metrics
 
 OUTPUT_DIR = Path(__file__).resolve().parents[2] / "outputs" / "finetune"
 BATCH_SIZES = {"ENZYMES": 32, "PTC_MR": 32, "Cora_NC": -1, "CiteSeer_NC": -1, "Cora_LP": 256, "CiteSeer_LP": 256}
 EPOCHS = {"ENZYMES": 100, "PTC_MR": 100, "Cora_NC": 200, "CiteSeer_NC": 200, "Cora_LP": 300, "CiteSeer_LP": 300}
+HARD_NEGATIVE_RATIO = 0.3
+MIN_HARD_NEGATIVES = 8
 PATIENCE_FRACTION = 0.5
+
+
+class LinkPredictionHardNegativeMiner:
+    """finetune.py:45-106.  The top-k half (normalise, n x n similarity, mask, top-k) is one libgnnmp call
+    (csrc/hardneg.hip) that never materialises the index lists of the ~n^2 candidate pairs; ties between equal scores go
+    to the lower flat index i*n+j (torch.topk leaves them unspecified).  The random remainder -- reached only when 30 %
+    of the candidate pairs is fewer than the batch, i.e. on graphs of a few dozen nodes -- follows the reference with
+    torch index ops on the device."""
+
+    def __init__(self) -> None:
+        self._count_key, self._count = None, 0
+
+    def _num_potential(self, num_nodes: int, existing_edges: Tensor) -> int:
+        """|{(i, j): i != j, (i, j) and (j, i) not in existing_edges}|; one sync per distinct edge tensor."""
+        key = (existing_edges.data_ptr(), tuple(existing_edges.shape), num_nodes)
+        if key != self._count_key:
+            s, d = existing_edges[0], existing_edges[1]
+            off = s != d
+            pairs = torch.cat([s[off] * num_nodes + d[off], d[off] * num_nodes + s[off]])
+            self._count = num_nodes * num_nodes - num_nodes - int(torch.unique(pairs).numel())
+            self._count_key = key
+        return self._count
+
+    def mine_hard_negatives_for_edges(self, node_embeddings: Tensor, positive_edges: Tensor, num_negatives: int,
+                                      existing_edges: Tensor) -> Tensor:
+        device, n = node_embeddings.device, node_embeddings.size(0)
+        potential = self._num_potential(n, existing_edges)
+        if potential == 0:
+            return torch.empty(2, 0, dtype=torch.long, device=device)
+        num_hard = max(MIN_HARD_NEGATIVES, int(potential * HARD_NEGATIVE_RATIO))
+        num_hard = min(num_hard, potential, num_negatives)
+        hard = ops.hard_negative_topk(node_embeddings.contiguous(), existing_edges.contiguous(), num_hard)
+        remaining = num_negatives - num_hard
+        if remaining <= 0:
+            return hard
+        mask = torch.ones(n, n, dtype=torch.bool, device=device)            # finetune.py:80-104 (small graphs only)
+        mask[existing_edges[0], existing_edges[1]] = False
+        mask[existing_edges[1], existing_edges[0]] = False
+        mask.fill_diagonal_(False)
+        mask[hard[0], hard[1]] = False
+        mask[hard[1], hard[0]] = False
+        rs, rd = torch.where(mask)
+        if rs.numel() == 0:
+            return hard
+        pick = torch.randperm(rs.numel(), device=device)[:min(remaining, rs.numel())]
+        rand = torch.stack([rs[pick], rd[pick]], dim=0)
+        return torch.cat([hard, rand], dim=1) if num_hard > 0 else rand
 
 
 @dataclass
@@ -44,75 +95,161 @@ class FinetuneConfig:
         self.patience = int(self.epochs * PATIENCE_FRACTION)
 
 
-def classification_loss(logits: torch.Tensor, targets: torch.Tensor, num_classes: int) -> torch.Tensor:
+def set_global_seed(seed: int) -> None:
+    torch.manual_seed(seed)
+
+
+def classification_loss(logits: Tensor, targets: Tensor, num_classes: int) -> Tensor:
     """finetune.py:150-158 / 169-177: CE (mean), or BCE-with-logits on logits[:,1] for binary domains."""
     if num_classes == 2:
         return torch.nn.functional.binary_cross_entropy_with_logits(logits[:, 1], targets.float())
     return O.cross_entropy_sum(logits, targets) / targets.numel()
 
 
-def process_batch(model: FinetuneGNN, batch, device, task_type: str, domain_name: str):
+class _DeviceCache:
+    """The single graph of the node / link tasks and the message-passing edges are moved to the GPU once, not per batch
+    (the reference re-sends `data.to(device)` every batch, finetune.py:164,184)."""
+
+    def __init__(self) -> None:
+        self._items: Dict[int, object] = {}
+
+    def get(self, obj, device):
+        k = id(obj)
+        if k not in self._items:
+            self._items[k] = (obj, obj.to(device))          # keep `obj` alive so ids are not reused
+        return self._items[k][1]
+
+
+_CACHE = _DeviceCache()
+
+
+def process_batch(model: FinetuneGNN, batch, device, task_type: str, domain_name: str,
+                  hard_negative_miner: Optional[LinkPredictionHardNegativeMiner],
+                  train_edges_for_hard_mining: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """finetune.py:136-211 -> (loss, targets, predictions, probabilities)."""
     if task_type == "graph_classification":
         b = batch.to(device)
-        logits = model(b)
-        return classification_loss(logits, b.y, NUM_CLASSES[domain_name]), logits
-    if task_type == "node_classification":
-        data, idx, targets = batch
-        logits = O.take_rows(model(data), idx)
-        return classification_loss(logits, targets, NUM_CLASSES[domain_name]), logits
-    raise NotImplementedError("link-prediction fine-tuning (hard-negative miner) is a later row of SURVEY section 8f")
+        logits, targets = model(b), b.y
+    elif task_type == "node_classification":
+        data, node_indices, targets = batch
+        data, node_indices, targets = _CACHE.get(data, device), node_indices.to(device), targets.to(device)
+        logits = O.take_rows(model(data, message_passing_edges=train_edges_for_hard_mining), node_indices)
+    else:
+        if model.training:
+            data, pos_edges, _ = batch
+            data, pos_edges = _CACHE.get(data, device), pos_edges.to(device).contiguous()
+            with torch.no_grad():
+                emb = model.gnn_backbone(model.input_encoder(data.x), train_edges_for_hard_mining)
+            neg_edges = hard_negative_miner.mine_hard_negatives_for_edges(
+                node_embeddings=emb, positive_edges=pos_edges, num_negatives=pos_edges.size(1),
+                existing_edges=train_edges_for_hard_mining)
+            all_edges = torch.cat([pos_edges, neg_edges], dim=1)
+            edge_labels = torch.cat([torch.ones(pos_edges.size(1), device=device), torch.zeros(neg_edges.size(1), device=device)])
+        else:
+            data, all_edges, edge_labels = batch
+            data, all_edges, edge_labels = _CACHE.get(data, device), all_edges.to(device).contiguous(), edge_labels.to(device)
+        probs = model(data, edge_index=all_edges, message_passing_edges=train_edges_for_hard_mining)
+        loss = O.binary_cross_entropy_sum(probs, edge_labels) / edge_labels.numel()
+        p = probs.detach()
+        return loss, edge_labels.long(), (p > 0.5).long(), torch.stack([1 - p, p], dim=1)
+    loss = classification_loss(logits, targets, NUM_CLASSES[domain_name])
+    lg = logits.detach()
+    return loss, targets, lg.argmax(dim=1), torch.softmax(lg, dim=1)
 
 
-def finetune(cfg: FinetuneConfig, epochs: Optional[int] = None, device: Optional[str] = None) -> float:
-    torch.manual_seed(cfg.seed)
-    gen = torch.Generator().manual_seed(cfg.seed)
+def compute_loss_and_metrics(model, batch, device, task_type: str, domain_name: str, prefix: str, miner,
+                             train_edges: Optional[Tensor]) -> Dict[str, float]:
+    model.eval()
+    with torch.no_grad():
+        loss, targets, predictions, probabilities = process_batch(model, batch, device, task_type, domain_name, miner, train_edges)
+    return compute_batch_metrics(domain_name, targets, predictions, probabilities, loss, prefix)
+
+
+class JsonlLogger:
+    def __init__(self, path: Optional[str]) -> None:
+        self.f = open(path, "a") if path else None
+
+    def log(self, metrics: Dict, step: int) -> None:
+        if self.f:
+            self.f.write(json.dumps({"step": step, **metrics}) + "\n")
+            self.f.flush()
+
+
+def _train_edges(loader, device) -> Optional[Tensor]:
+    e = getattr(loader.dataset, "train_edges", None)
+    return None if e is None else _CACHE.get(e, device).contiguous()
+
+
+def run_training(model: FinetuneGNN, optimizer, train_loader, device, epoch: int, global_step: List[int],
+                 cfg: FinetuneConfig, miner, logger: JsonlLogger) -> None:
+    """finetune.py:283-331"""
+    model.train()
+    for batch in train_loader:
+        t0 = time.time()
+        global_step[0] += 1
+        loss, targets, predictions, probabilities = process_batch(model, batch, device, cfg.task_type, cfg.domain_name,
+                                                                   miner, _train_edges(train_loader, device))
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        if logger.f:
+            logger.log(compute_training_metrics(epoch, global_step[0], loss, optimizer, cfg.domain_name, targets, predictions,
+                                                probabilities, t0, model), global_step[0])
+
+
+def evaluate(model: FinetuneGNN, loader, device, cfg: FinetuneConfig, prefix: str, miner, train_edges) -> List[Dict[str, float]]:
+    return [compute_loss_and_metrics(model, b, device, cfg.task_type, cfg.domain_name, prefix, miner, train_edges) for b in loader]
+
+
+def finetune(cfg: FinetuneConfig, epochs: Optional[int] = None, device: Optional[str] = None,
+             data_root: Optional[str] = None, data_scale: float = 1.0, log_path: Optional[str] = None) -> Dict[str, float]:
+    """finetune.py:334-445.  Returns the test metrics of the best-validation checkpoint."""
+    from ..data.data_setup import ensure_processed
+    from ..data.finetune_data_loaders import create_finetune_data_loader
+    from .._host import limit_host_threads
+    limit_host_threads(1)
+    start = time.time()
+    set_global_seed(cfg.seed)
+    gen = torch.Generator()
+    gen.manual_seed(cfg.seed)
     if device is None:
         if not torch.cuda.is_available():
             raise RuntimeError("the HIP path needs a GPU (no CPU fallback)")
         device = "cuda"
     dev = torch.device(device)
-    model = create_finetune_model(dev, cfg)
-    opt = torch.optim.AdamW(model.param_groups)
-    dim, ncls = DOMAIN_DIMENSIONS[cfg.domain_name], NUM_CLASSES[cfg.domain_name]
-    if cfg.task_type == "node_classification":
-        n = 2708 if cfg.domain_name.startswith("Cora") else 3327
-        g = S.cora_like(gen, num_nodes=n, undirected_edges=5429 if n == 2708 else 4552, dim=dim, num_classes=ncls)
-        data = Batch.from_data_list([g]).to(dev)
-        perm = torch.randperm(n, generator=gen)
-        y = g.y.to(dev)
-        train = [(data, perm[:20 * ncls].to(dev), y[perm[:20 * ncls]])]
-        val = [(data, perm[20 * ncls:20 * ncls + 500].to(dev), y[perm[20 * ncls:20 * ncls + 500]])]
-    else:
-        mk = lambda k: [Batch.from_data_list([S.random_graph(gen, dim, num_classes=ncls) for _ in range(cfg.batch_size)]) for _ in range(k)]
-        train, val = mk(15), mk(2)
     OUTPUT_DIR.mkdir(parents=True, exist_ok=True)
     path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"
-    best, stale, t0 = -1.0, 0, time.time()
+    root = Path(data_root) if data_root else None
+    ensure_processed([cfg.domain_name], root, data_scale)
+    val_loader = create_finetune_data_loader(cfg.domain_name, "val", cfg.batch_size, gen, root)
+    test_loader = create_finetune_data_loader(cfg.domain_name, "test", cfg.batch_size, gen, root)
+    train_loader = create_finetune_data_loader(cfg.domain_name, "train", cfg.batch_size, gen, root)
+    model = create_finetune_model(dev, cfg)
+    optimizer = torch.optim.AdamW(model.param_groups)
+    miner = LinkPredictionHardNegativeMiner() if cfg.task_type == "link_prediction" else None
+    logger = JsonlLogger(log_path)
+    torch.save({"epoch": 0, "model_state_dict": model.state_dict(), "val_metrics": {}}, path)
+    key = "val/auc" if cfg.task_type == "link_prediction" else "val/accuracy"
+    best, stale, global_step, epoch = -float("inf"), 0, [0], 0
     for epoch in range(1, (epochs or cfg.epochs) + 1):
-        model.train()
-        for batch in train:
-            loss, _ = process_batch(model, batch, dev, cfg.task_type, cfg.domain_name)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-        model.eval()
-        correct = total = 0
-        with torch.no_grad():
-            for batch in val:
-                _, logits = process_batch(model, batch, dev, cfg.task_type, cfg.domain_name)
-                tgt = batch[2] if cfg.task_type == "node_classification" else batch.y.to(dev)
-                correct += int((logits.argmax(1) == tgt).sum())
-                total += tgt.numel()
-        acc = correct / max(total, 1)
-        if acc > best:
-            best, stale = acc, 0
-            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "val_metrics": {"val/accuracy": acc}}, path)
+        run_training(model, optimizer, train_loader, dev, epoch, global_step, cfg, miner, logger)
+        edges = _train_edges(train_loader, dev)
+        val = compute_validation_metrics(evaluate(model, val_loader, dev, cfg, "val", miner, edges), epoch)
+        if val[key] > best:
+            best, stale = val[key], 0
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "val_metrics": val}, path)
         else:
             stale += 1
+        logger.log(val, global_step[0])
         if stale >= cfg.patience:
             break
-    print(f"{cfg.exp_name}: best val accuracy {best:.4f}, training_time {time.time() - t0:.2f}s, saved {path}")
-    return best
+    model.load_state_dict(torch.load(path, map_location=dev, weights_only=True)["model_state_dict"])
+    test = compute_test_metrics(evaluate(model, test_loader, dev, cfg, "test", miner, _train_edges(train_loader, dev)),
+                                epoch, stale, start, model)
+    logger.log(test, global_step[0])
+    print(f"{cfg.exp_name}: best {key} {best:.4f}, test/accuracy {test['test/accuracy']:.4f}, test/auc {test['test/auc']:.4f}, "
+          f"training_time {test['test/training_time']:.2f}s, saved {path}")
+    return test
 
 
 def main() -> None:
@@ -123,8 +260,12 @@ def main() -> None:
     p.add_argument("--seed", type=int, required=True)
     p.add_argument("--epochs", type=int, default=None)
     p.add_argument("--device", type=str, default=None)
+    p.add_argument("--data-root", type=str, default=None)
+    p.add_argument("--data-scale", type=float, default=1.0)
+    p.add_argument("--log", type=str, default=None)
     a = p.parse_args()
-    finetune(FinetuneConfig(a.domain_name, a.finetune_strategy, a.pretrained_scheme, a.seed), a.epochs, a.device)
+    finetune(FinetuneConfig(a.domain_name, a.finetune_strategy, a.pretrained_scheme, a.seed), a.epochs, a.device,
+             a.data_root, a.data_scale, a.log)
 
 
 if __name__ == "__main__":

@@ -304,6 +304,29 @@ def nt_xent_bwd(z1: Tensor, z2: Tensor, temperature: float, g_scale: Tensor, ws:
     return g1, g2
 
 
+def hard_negative_topk(emb: Tensor, existing_edges: Tensor, k: int, return_scores: bool = False,
+                       return_matrix: bool = False):
+    """Top-k cosine-similarity non-edges (finetune.py:45-75).  Returns edges [2,k] int64 (score-descending), and
+    optionally the selected scores [k] and the masked n x n similarity matrix."""
+    _need(emb, torch.float32, "emb", 2); _need(existing_edges, torch.int64, "existing_edges", 2)
+    n, d = emb.shape
+    E = existing_edges.size(1)
+    l = L.lib()
+    ws = _ws(l.gmp_hard_negative_workspace_bytes(n, d), emb.device)
+    out = torch.empty(2, k, dtype=torch.int64, device=emb.device)
+    sc = torch.empty(k, dtype=torch.float32, device=emb.device) if return_scores else None
+    mat = torch.empty(n, n, dtype=torch.float32, device=emb.device) if return_matrix else None
+    L.check(l.gmp_hard_negative_topk(_ptr(emb), n, d, _ptr(existing_edges) if E else None, E, k, _ptr(out) if k else None,
+                                     _ptr(sc) if sc is not None else None, _ptr(mat) if mat is not None else None,
+                                     _ptr(ws), ws.numel(), _stream(emb)), "gmp_hard_negative_topk")
+    res = (out,)
+    if return_scores:
+        res += (sc,)
+    if return_matrix:
+        res += (mat,)
+    return res if len(res) > 1 else out
+
+
 def dropout_fwd(x: Tensor, p: float, seed: int, stream_id: int) -> Tensor:
     _need(x, torch.float32, "x")
     if x.numel() % 4:

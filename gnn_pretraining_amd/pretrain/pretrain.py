@@ -1,8 +1,10 @@
 """Pre-training driver: same scheme tables, step ordering and CLI as src/pretrain/pretrain.py
-(``--exp_name S --seed N``), running on libgnnmp with synthetic batches (the TUDataset downloads
+(``--exp_name S --seed N``), running on libgnnmp over the loaders of gnn_pretraining_amd/data (processed
+datasets in data/processed; synthetic stand-ins are generated when none were exported, since the TUDataset downloads
 of the reference need the network).  wandb is replaced by a JSONL logger with the same metric keys.
 
-Build-only flags (the reference's flags are unchanged): --epochs, --steps-per-epoch, --log, --device.
+Build-only flags (the reference's flags are unchanged): --epochs, --steps-per-epoch, --log, --device, --data-root,
+--data-scale, --rng, --module-path.
 """
 from __future__ import annotations
 
@@ -18,7 +20,6 @@ import torch
 
 from ..constants import PRETRAIN_TUDATASETS
 from ..models.pretrain_model import PretrainableGNN
-from .. import synthetic
 from .control import AdaptiveLossBalancer, GradientSurgery, GRLScheduler, TaskSpecificOptimizer, TemperatureScheduler
 from .tasks import BasePretrainTask, instantiate_tasks
 
@@ -107,17 +108,25 @@ class JsonlLogger:
             self.f.flush()
 
 
-def run_training_engine(state: StepState, engine, steps: int, generator: torch.Generator, device, epoch: int,
-                        global_step: List[int], logger: JsonlLogger, log_every: int = 50) -> None:
-    """run_training on the stacked-step engine: same step semantics, one fused forward/backward per step.
-    Losses are read back only every `log_every` steps (the reference syncs ~2,000 times per step to log)."""
-    from ..engine import StepInputs
+def run_training_engine(state: StepState, engine, train_loader, generator: torch.Generator, device, epoch: int,
+                        global_step: List[int], logger: JsonlLogger, log_every: int = 50, max_steps: Optional[int] = None) -> None:
+    """run_training (pretrain.py:99-190) on the stacked-step engine: same step semantics, one fused forward/backward
+    per step.  A background thread walks the loader and draws the step's index data (sampler and task draws share
+    the CPU generator and keep the reference's order: only that thread touches it during the epoch); losses are read
+    back only every `log_every` steps (the reference syncs ~2,000 times per step to log)."""
+    from ..engine import StepInputs, StepPrefetcher
     state.model.train()
-    for _ in range(steps):
+
+    def inputs():
+        for k, batches in enumerate(train_loader):
+            if max_steps is not None and k >= max_steps:
+                return
+            yield StepInputs(batches, device, engine.dpad)
+
+    for inp, prepared in StepPrefetcher(engine, inputs(), generator):
         global_step[0] += 1
-        inp = StepInputs(synthetic.pretrain_step_batches(generator, state.cfg.pretrain_domains), device, engine.dpad)
         engine.temperature, engine.grl_lambda = state.temperature(), state.grl()
-        engine.step(inp, generator)
+        engine.step(inp, generator, prepared=prepared)
         state.grl.step()
         state.temperature.step()
         if global_step[0] % log_every == 0:
@@ -128,12 +137,15 @@ def run_training_engine(state: StepState, engine, steps: int, generator: torch.G
             logger.log(m, global_step[0])
 
 
-def run_training(state: StepState, steps: int, generator: torch.Generator, device, epoch: int, global_step: List[int],
-                 logger: JsonlLogger) -> None:
+def run_training(state: StepState, train_loader, generator: torch.Generator, device, epoch: int, global_step: List[int],
+                 logger: JsonlLogger, max_steps: Optional[int] = None) -> None:
+    """The same loop through the nn.Module path (one autograd graph per task); kept as the readable twin of the engine."""
     state.model.train()
-    for _ in range(steps):
+    for k, host_batches in enumerate(train_loader):
+        if max_steps is not None and k >= max_steps:
+            break
         global_step[0] += 1
-        batches = {d: b.to(device) for d, b in synthetic.pretrain_step_batches(generator, state.cfg.pretrain_domains).items()}
+        batches = {d: b.to(device) for d, b in host_batches.items()}
         per_task, per_domain, total, gs = train_step(state, batches, generator)
         m = {f"train/loss/{t}": float(v.detach()) for t, v in per_task.items()}
         for t, dd in per_domain.items():
@@ -148,26 +160,40 @@ def run_training(state: StepState, steps: int, generator: torch.Generator, devic
 
 
 @torch.no_grad()
-def run_evaluation(state: StepState, generator: torch.Generator, device, val_steps: int = 2) -> float:
-    """pretrain.py:193-281 on synthetic validation batches: every task x every domain, eval mode, the shared
-    generator advances (the reference's evaluation is stochastic too)."""
+def run_evaluation(state: StepState, val_loaders, generator: torch.Generator, device) -> Dict[str, float]:
+    """pretrain.py:193-281: every task over every domain's whole validation loader, eval mode, the shared generator
+    advances (the reference's evaluation is stochastic too); per-domain mean over batches, per-task mean over domains,
+    total through the loss balancer.  Returns the reference's val/* metric dictionary."""
     state.model.eval()
-    per_task = {}
+    per_task, per_dt = {}, {d: {} for d in val_loaders}
     for name, task in state.tasks.items():
         dom = []
-        for d in state.cfg.pretrain_domains:
-            losses = []
-            for _ in range(val_steps):
-                b = synthetic.pretrain_step_batches(generator, [d], graphs_per_domain=BATCH_SIZE)[d].to(device)
-                losses.append(task.compute_loss({d: b}, generator)[0])
+        for d, loader in val_loaders.items():
+            losses = [task.compute_loss({d: b.to(device)}, generator)[0] for b in loader]
             dom.append(torch.stack(losses).mean())
+            per_dt[d][name] = float(dom[-1])
         per_task[name] = torch.stack(dom).mean()
     main = {k: v for k, v in per_task.items() if k != "domain_adv"}
-    return float(state.balancer.balance_losses(main, state.grl()))
+    total = state.balancer.balance_losses(main, state.grl())
+    m = {f"val/loss/{d}/{t}": v for d, tt in per_dt.items() for t, v in tt.items()}
+    m.update({f"val/loss/{t}": float(v) for t, v in per_task.items()})
+    m.update({f"val/loss/{d}": sum(tt.values()) / len(tt) for d, tt in per_dt.items()})
+    m["val/loss/total"] = float(total)
+    if "domain_adv" in per_task:
+        m["val/domain_adv/loss"] = float(per_task["domain_adv"])
+    return m
 
 
-def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: int = 462, log_path: Optional[str] = None,
-             device: Optional[str] = None) -> Path:
+def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: Optional[int] = None, log_path: Optional[str] = None,
+             device: Optional[str] = None, data_root: Optional[str] = None, data_scale: float = 1.0,
+             rng_mode: str = "reference", use_engine: bool = True) -> Path:
+    """pretrain.py:284-349.  `steps_per_epoch` truncates an epoch (the loader's own length -- 462 for the four-domain
+    schemes on the real data -- is the default); data come from data/processed (synthetic stand-ins are generated on
+    first use when no exported real data is there)."""
+    from ..data.data_setup import ensure_processed
+    from ..data.pretrain_data_loaders import create_train_data_loader, create_val_data_loader
+    from .._host import limit_host_threads
+    limit_host_threads(1)
     set_global_seed(cfg.seed)
     generator = torch.Generator()
     generator.manual_seed(cfg.seed)
@@ -177,26 +203,36 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: int = 4
         device = "cuda"
     dev = torch.device(device)
     OUTPUT_DIR.mkdir(parents=True, exist_ok=True)
+    root = Path(data_root) if data_root else None
+    ensure_processed(cfg.pretrain_domains, root, data_scale)
+    val_loaders = {d: create_val_data_loader(d, generator, root) for d in cfg.pretrain_domains}
+    train_loader = create_train_data_loader(cfg.pretrain_domains, generator, root)
+    steps = min(len(train_loader), steps_per_epoch) if steps_per_epoch else len(train_loader)
     model = PretrainableGNN(device=dev, domain_names=cfg.pretrain_domains, task_names=cfg.active_tasks)
-    state = StepState(model, cfg, steps_per_epoch, epochs)
+    state = StepState(model, cfg, steps, epochs)
     logger = JsonlLogger(log_path)
     engine = None
     from ..engine import SUPPORTED_TASKS, StepEngine
-    if all(t in SUPPORTED_TASKS for t in cfg.active_tasks):
-        engine = StepEngine(model, cfg.active_tasks, cfg.pretrain_domains, dev, seed=cfg.seed)
+    if use_engine and all(t in SUPPORTED_TASKS for t in cfg.active_tasks):
+        engine = StepEngine(model, cfg.active_tasks, cfg.pretrain_domains, dev, seed=cfg.seed, rng_mode=rng_mode,
+                            max_rows=32768, max_edges=262144)
     best, stale, global_step = float("inf"), 0, [0]
     path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"
     for epoch in range(1, epochs + 1):
         t0 = time.time()
         if engine is not None:
-            run_training_engine(state, engine, steps_per_epoch, generator, dev, epoch, global_step, logger)
+            run_training_engine(state, engine, train_loader, generator, dev, epoch, global_step, logger, max_steps=steps)
         else:
-            run_training(state, steps_per_epoch, generator, dev, epoch, global_step, logger)
-        val = run_evaluation(state, generator, dev)
-        logger.log({"val/loss/total": val, "epoch_seconds": time.time() - t0}, global_step[0])
-        if val < best:
-            best, stale = val, 0
-            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "val_metrics": {"val/loss/total": val}}, path)
+            run_training(state, train_loader, generator, dev, epoch, global_step, logger, max_steps=steps)
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        t1 = time.time()
+        val = run_evaluation(state, val_loaders, generator, dev)
+        val.update({"epoch_seconds": time.time() - t0, "train_seconds": t1 - t0, "train_graphs_per_s": steps * BATCH_SIZE / (t1 - t0)})
+        logger.log(val, global_step[0])
+        if val["val/loss/total"] < best:
+            best, stale = val["val/loss/total"], 0
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                        "val_metrics": {k: v for k, v in val.items() if k.startswith("val/")}}, path)
         else:
             stale += 1
         if stale >= int(epochs * PATIENCE_FRACTION):
@@ -209,11 +245,16 @@ def main() -> None:
     p.add_argument("--exp_name", type=str, required=True)
     p.add_argument("--seed", type=int, required=True)
     p.add_argument("--epochs", type=int, default=EPOCHS)
-    p.add_argument("--steps-per-epoch", type=int, default=462)
+    p.add_argument("--steps-per-epoch", type=int, default=None, help="truncate epochs (default: the loader's length)")
     p.add_argument("--log", type=str, default=None)
     p.add_argument("--device", type=str, default=None)
+    p.add_argument("--data-root", type=str, default=None, help="directory holding {D}/data.safetensors (default data/processed)")
+    p.add_argument("--data-scale", type=float, default=1.0, help="size of the synthetic stand-ins generated on first use")
+    p.add_argument("--rng", choices=["reference", "vectorized"], default="reference")
+    p.add_argument("--module-path", action="store_true", help="run the per-task nn.Module path instead of the stacked engine")
     a = p.parse_args()
-    path = pretrain(PretrainConfig(exp_name=a.exp_name, seed=a.seed), a.epochs, a.steps_per_epoch, a.log, a.device)
+    path = pretrain(PretrainConfig(exp_name=a.exp_name, seed=a.seed), a.epochs, a.steps_per_epoch, a.log, a.device,
+                    a.data_root, a.data_scale, a.rng, not a.module_path)
     print(f"saved {path}")
 
 

@@ -268,6 +268,26 @@ int gmp_row_fill(float* dst, const int64_t* idx, const float* src, int64_t num_i
                  int feat, int broadcast, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Hard-negative mining for link-prediction fine-tuning
+ * (finetune.py:45-75, LinkPredictionHardNegativeMiner.mine_hard_negatives_for_edges; called per
+ * training batch from finetune.py:190-196).
+ *   zn = F.normalize(emb, dim=1) (eps 1e-12); S = zn zn^T; pairs (s,d) and (d,s) of
+ *   existing_edges ([2,E] int64, row 0 = sources) and the diagonal are excluded;
+ *   out_edges [2,k] int64 = the k highest-scoring remaining ordered pairs (i,j), sorted by score
+ *   descending -- what torch.topk(potential_scores, k) + potential_indices gives.  Ties (S is
+ *   symmetric, so every score appears twice) are broken by the LOWER flat index i*n+j; torch.topk
+ *   leaves that order unspecified.
+ *   out_scores: NULL or [k] float, the selected scores.  scores_out: NULL or [n,n] float, receives the
+ *   masked similarity matrix (masked entries = -inf) -- test / diagnostic hook.
+ *   The caller guarantees k <= number of unmasked pairs (finetune.py:66-67 clamps it); n <= 65535,
+ *   k <= 4096.  workspace >= gmp_hard_negative_workspace_bytes(n, dim).
+ * ------------------------------------------------------------------------- */
+size_t gmp_hard_negative_workspace_bytes(int64_t n, int64_t dim);
+int gmp_hard_negative_topk(const float* emb, int64_t n, int64_t dim, const int64_t* existing_edges, int64_t E,
+                           int64_t k, int64_t* out_edges, float* out_scores, float* scores_out,
+                           void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one
  * launch.  Features of all domains sit padded to `dpad` (<= 64) columns in x_all [R, dpad]; stacked row
  * r reads x_all[src_row[r]]; segment s belongs to domain seg_dom[s] (weights at params + w_off_host[d],

@@ -22,5 +22,10 @@ Pinning status:
     requirements.txt:3), which is absent from /root/reference and not
     installable here; the reference ships no tests or fixtures for them.
     Their restatement follows PyG's published semantics and is
-    **parity unpinned** at that boundary.
+    **parity unpinned** at that boundary;
+  * graph_properties.py (the 12 graph-property targets) calls networkx, the
+    library the reference itself calls, function for function; miner.py (the
+    fine-tune hard-negative miner) is a line-by-line torch-CPU restatement.
+    The reference holds no fixture for either: **parity unpinned** beyond the
+    closed-form cases in tests/test_data.py / tests/test_gpu_miner.py.
 """

@@ -22,7 +22,9 @@ def run_one(job):
            "--pretrained_scheme", scheme, "--seed", str(seed)] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     if r.returncode:
+        print(f"x Failed: {domain} {strategy} {scheme} (seed={seed})")
         return False, job, f"Exit code {r.returncode}: {r.stderr}"
+    print(f"ok Completed: {domain} {strategy} {scheme} (seed={seed}) {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ''}")
     return True, job, None
 
 
