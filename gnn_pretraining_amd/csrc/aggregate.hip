@@ -180,6 +180,118 @@ __global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* 
     }
 }
 
+// LDS-resident tile form.  The kernel above leaves every neighbour read to L1/L2: per launch ~4.8 KiB of x rows per
+// output row cross the L2->CU fabric (10.4 GB reads + 2.2 GB writes in 1.1 ms ~ 11.5 TB/s), which is what bounds it,
+// not HBM.  Here a workgroup copies its tile of TILE consecutive rows (TILE KiB) into LDS once -- fully coalesced, one
+// pass over x -- and neighbour rows that fall inside the tile (almost all: a tile spans ~4 whole graphs, and edges never
+// leave a graph) are read from LDS; only the graphs cut by a tile border reach into global memory.  The next tile's
+// rows / rowptr / col are prefetched into registers while the current tile is being reduced, so HBM stays busy during
+// the LDS phase; the output leaves with non-temporal stores.
+template <int SB, int TILE, int CCAP, bool NT_STORE>
+__global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
+                                                                   const int* __restrict__ col, const float* __restrict__ eps,
+                                                                   float4* __restrict__ out, int64_t nrows, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_x = reinterpret_cast<float4*>(smem);
+    int* s_col = reinterpret_cast<int*>(smem + (size_t)TILE * 1024);
+    int* s_ptr = s_col + CCAP;
+    constexpr int SWAVES = SB / GMP_WAVE;
+    constexpr int XPT = TILE * 64 / SB;          // float4 of the tile per thread
+    constexpr int CPT = CCAP / SB;
+    static_assert(TILE * 64 % SB == 0 && CCAP % SB == 0 && TILE + 1 <= SB, "tile shape");
+    const int per_xcd = gridDim.x / NUM_XCD;
+    const int lb = (blockIdx.x % NUM_XCD) * per_xcd + blockIdx.x / NUM_XCD;
+    const int lane = threadIdx.x % GMP_WAVE, wv = threadIdx.x / GMP_WAVE;
+    const float scale = 1.f + (eps ? eps[0] : 0.f);
+    const int64_t ntiles = (nrows + TILE - 1) / TILE;
+    const int64_t t0 = (int64_t)lb * tiles_per_block;
+    const int64_t tend = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+    if (t0 >= tend) return;
+
+    float4 px[XPT];
+    int pc[CPT];
+    int pp = 0, pbase = 0, pcnt = 0;
+#define GMP_PREFETCH_TILE(T, BASE, END)                                                        \
+    do {                                                                                       \
+        const int64_t pr0 = (T) * TILE;                                                        \
+        const int pnr = (int)(nrows - pr0 < TILE ? nrows - pr0 : TILE);                        \
+        _Pragma("unroll") for (int k = 0; k < XPT; ++k) {                                      \
+            const int i = threadIdx.x + k * SB;                                                \
+            px[k] = i < pnr * 64 ? x[pr0 * 64 + i] : make_float4(0.f, 0.f, 0.f, 0.f);          \
+        }                                                                                      \
+        pp = (int)threadIdx.x <= pnr ? rowptr[pr0 + threadIdx.x] : 0;                          \
+        pbase = (BASE);                                                                        \
+        pcnt = (END) - pbase;                                                                  \
+        _Pragma("unroll") for (int k = 0; k < CPT; ++k) {                                      \
+            const int i = threadIdx.x + k * SB;                                                \
+            pc[k] = (pcnt <= CCAP && i < pcnt) ? col[pbase + i] : 0;                           \
+        }                                                                                      \
+    } while (0)
+    // tile borders in col, read two tiles ahead so the (scalar, uncached) loads never stall the col prefetch
+    auto border = [&](int64_t k) -> int { return rowptr[k * TILE < nrows ? k * TILE : nrows]; };
+    int eB = border(t0 + 1), eC = border(t0 + 2);
+    GMP_PREFETCH_TILE(t0, border(t0), eB);
+    for (int64_t t = t0; t < tend; ++t) {
+        const int eD = border(t + 3);
+        const int64_t r0 = t * TILE;
+        const int nr = (int)(nrows - r0 < TILE ? nrows - r0 : TILE);
+        const int base = pbase, cnt = pcnt;
+        const bool staged = cnt <= CCAP;
+        __syncthreads();                                   // the previous tile's LDS is no longer read
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) {
+            const int i = threadIdx.x + k * SB;
+            if (i < nr * 64) s_x[i] = px[k];
+        }
+        if ((int)threadIdx.x <= nr) s_ptr[threadIdx.x] = pp;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int i = threadIdx.x + k * SB;
+                if (i < cnt) s_col[i] = pc[k];
+            }
+        }
+        __syncthreads();
+        if (t + 1 < tend) GMP_PREFETCH_TILE(t + 1, eB, eC);   // in flight while this tile is reduced out of LDS
+        const int r0i = (int)r0;
+        auto row_of = [&](int u) -> float4 {
+            const unsigned loc = (unsigned)(u - r0i);
+            return loc < (unsigned)nr ? s_x[loc * 64 + lane] : x[(int64_t)u * 64 + lane];
+        };
+        for (int rr = wv; rr < nr; rr += SWAVES) {
+            const int start = s_ptr[rr], end = s_ptr[rr + 1];
+            float4 acc = s_x[rr * 64 + lane];
+            acc = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
+            int e = start;
+            for (; e + 4 <= end; e += 4) {
+                int c0, c1, c2, c3;
+                if (staged) { c0 = s_col[e - base]; c1 = s_col[e - base + 1]; c2 = s_col[e - base + 2]; c3 = s_col[e - base + 3]; }
+                else { c0 = col[e]; c1 = col[e + 1]; c2 = col[e + 2]; c3 = col[e + 3]; }
+                const float4 a = row_of(__builtin_amdgcn_readfirstlane(c0)), b = row_of(__builtin_amdgcn_readfirstlane(c1));
+                const float4 c = row_of(__builtin_amdgcn_readfirstlane(c2)), d = row_of(__builtin_amdgcn_readfirstlane(c3));
+                acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
+            }
+            for (; e < end; ++e) {
+                const int cc = staged ? s_col[e - base] : col[e];
+                acc = f4add(acc, row_of(__builtin_amdgcn_readfirstlane(cc)));
+            }
+            if (NT_STORE) {
+                float* o = reinterpret_cast<float*>(out + (r0 + rr) * 64 + lane);
+                __builtin_nontemporal_store(acc.x, o);
+                __builtin_nontemporal_store(acc.y, o + 1);
+                __builtin_nontemporal_store(acc.z, o + 2);
+                __builtin_nontemporal_store(acc.w, o + 3);
+            } else {
+                out[(r0 + rr) * 64 + lane] = acc;
+            }
+        }
+        eB = eC;
+        eC = eD;
+    }
+}
+
+#undef GMP_PREFETCH_TILE
+
 // any feature width: one thread per output element (class logits, 12 graph properties ...)
 __global__ __launch_bounds__(BLOCK) void seg_sum_scalar_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
                                                                const int* __restrict__ idx, float* __restrict__ out,
@@ -259,9 +371,11 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
     if (feat == 256 && N >= 65536) {          // working set beyond the caches: streaming kernel
-        // GMP_AGG_VARIANT (tuning aid): 0 = 1024 threads / 256-row tiles / nt stores, 1 = same with plain stores,
-        // 2 = 512-row tiles, 3 = 512 threads / 128-row tiles (default), 4 = 512 threads / 256-row tiles; GMP_AGG_BLOCKS = grid
-        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 3;
+        // GMP_AGG_VARIANT (tuning aid): 5 = LDS-resident 128-row tiles, 1024 threads, 1 block/CU (default); 6 = 64-row
+        // tiles, 512 threads, 2 blocks/CU; 8 = 5 with plain stores; cache-resident predecessors: 0 = 1024 threads /
+        // 256-row tiles / nt stores, 1 = same with plain stores, 2 = 512-row tiles, 3 = 512 threads / 128-row tiles,
+        // 4 = 512 threads / 256-row tiles.  GMP_AGG_BLOCKS = grid
+        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 5;
         static const int blocks_env = getenv("GMP_AGG_BLOCKS") ? atoi(getenv("GMP_AGG_BLOCKS")) : 0;
         hipStream_t st = (hipStream_t)stream;
 #define GMP_STREAM(SBV, TILEV, NTV, DEFBLOCKS)                                                                        \
@@ -272,14 +386,34 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
             hipLaunchKernelGGL((gin_aggregate_stream_kernel<SBV, TILEV, NTV>), dim3(blocks), dim3(SBV), 0, st,        \
                                (const float4*)x, rowptr, col, eps, (float4*)out, N, tpb);                            \
         } while (0)
+#define GMP_LDSTILE(SBV, TILEV, CCAPV, NTV, DEFBLOCKS)                                                                      \
+        do {                                                                                                          \
+            auto kern = gin_aggregate_ldstile_kernel<SBV, TILEV, CCAPV, NTV>;                                         \
+            const size_t lds = (size_t)TILEV * 1024 + (size_t)CCAPV * 4 + (size_t)(TILEV + 16) * 4;                   \
+            static bool attr_set = false;                                                                             \
+            if (!attr_set) {                                                                                          \
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_ldstile: LDS attribute: %s", hipGetErrorString(e)); \
+                attr_set = true;                                                                                      \
+            }                                                                                                         \
+            const int64_t ntiles = (N + TILEV - 1) / TILEV;                                                           \
+            int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \
+            int tpb = (int)((ntiles + blocks - 1) / blocks);                                                          \
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(SBV), lds, st, (const float4*)x, rowptr, col, eps,            \
+                               (float4*)out, N, tpb);                                                                 \
+        } while (0)
         switch (variant) {
+            case 5: GMP_LDSTILE(1024, 128, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
+            case 6: GMP_LDSTILE(512, 64, 1024, true, 512); return gmp::check_launch("gin_aggregate_ldstile_kernel");
+            case 8: GMP_LDSTILE(1024, 128, 2048, false, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 1: GMP_STREAM(1024, 256, false, 512); break;
             case 2: GMP_STREAM(1024, 512, true, 512); break;
             case 0: GMP_STREAM(1024, 256, true, 512); break;
             case 4: GMP_STREAM(512, 256, true, 1024); break;
-            default: GMP_STREAM(512, 128, true, 1024); break;   // best median of the sweep in profiles/README.md
+            default: GMP_STREAM(512, 128, true, 1024); break;
         }
 #undef GMP_STREAM
+#undef GMP_LDSTILE
         return gmp::check_launch("gin_aggregate_stream_kernel");
     }
     Plan p = make_plan(N);

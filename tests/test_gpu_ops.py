@@ -87,8 +87,8 @@ def test_gin_aggregate_fwd_bwd(graphs, F):
 
 
 def test_gin_aggregate_streaming_kernel():
-    """N >= 65,536 rows takes the LDS-staged streaming kernel (the roofline rung's path); a dense random graph
-    forces its un-staged fallback (more neighbour ids per 256-row tile than the LDS stage holds)."""
+    """N >= 65,536 rows takes the LDS-resident-tile kernel (the roofline rung's path); a dense random graph
+    forces its un-staged fallback (more neighbour ids per 128-row tile than the LDS stage holds)."""
     gen = torch.Generator().manual_seed(77)
     b = S.domain_batch(gen, 4, 2100)                        # ~69k rows of ENZYMES-shaped graphs
     n = b.num_nodes
@@ -104,6 +104,16 @@ def test_gin_aggregate_streaming_kernel():
     csr = ops.csr_build(ei.to(DEV), n2)
     out = ops.gin_aggregate_fwd(x2.to(DEV), csr.rowptr, csr.col, eps.to(DEV))
     close(out, OG.gin_aggregate(x2, ei, eps), what="streaming aggregate, un-staged tiles")
+    # staged tiles whose neighbours mostly lie OUTSIDE the LDS tile (global fallback per neighbour), a row count that is an
+    # exact multiple of the 128-row tile, isolated rows, eps = 0
+    n3 = 516 * 128
+    ei = torch.randint(0, n3, (2, 300_000), generator=gen)
+    ei = ei[:, (ei[1] % 7) != 0]                            # every 7th row has no incoming edge
+    x3 = torch.randn(n3, 256, generator=gen)
+    csr = ops.csr_build(ei.to(DEV), n3)
+    out = ops.gin_aggregate_fwd(x3.to(DEV), csr.rowptr, csr.col, torch.zeros(1, device=DEV))
+    close(out, OG.gin_aggregate(x3, ei, torch.zeros(1)), what="streaming aggregate, cross-tile neighbours")
+    assert torch.equal(out[::7].cpu(), x3[::7])
 
 
 def test_gin_aggregate_isolated_and_empty():
