@@ -75,6 +75,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_colsum": (C.c_int, [p, p, i64, i64, i64, i32, p, sz, p]),
     "gmp_bn_workspace_bytes": (sz, [i64, i32, i32, i64]),
     "gmp_bn_fwd": (C.c_int, [p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, C.POINTER(BnConfig), p, sz, p]),
+    "gmp_bn_running_update": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p]),
     "gmp_bn_bwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, p, p, p, p, p, i32,
                              C.POINTER(BnConfig), p, sz, p]),
     "gmp_lp_edge_features_fwd": (C.c_int, [p, p, p, i64, i64, i32, p]),
@@ -100,6 +101,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_encoder_bwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, i32, p, p, p, p, p, sz, p]),
     "gmp_step_desc_size": (sz, []),
     "gmp_pretrain_step_fwd_bwd": (C.c_int, [p, p, p, p]),
+    "gmp_step_phase_ms": (C.c_int, [p]),
     "gmp_mt_workspace_bytes": (sz, [i32]),
     "gmp_mt_pcgrad_clip_adamw": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
                                            f32, p, p, p, p, p, sz, i32, p]),

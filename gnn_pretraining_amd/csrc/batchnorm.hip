@@ -462,6 +462,23 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     return gmp::check_launch("bn_fwd kernels");
 }
 
+// The running-statistics half of a training-mode gmp_bn_fwd on its own: gmp_bn_fwd skips it when running_mean is NULL, so
+// a caller can keep it off its critical path (nothing reads running statistics during training) and apply it later from
+// the saved batch statistics -- same kernel, same order over segments, bit-identical result.
+extern "C" int gmp_bn_running_update(const int32_t* seg_ptr, const int32_t* seg_group, int S, int C, float* running_mean,
+                                     float* running_var, const float* save_mean, const float* save_rstd,
+                                     const gmp_bn_config* cfg, gmp_stream_t stream) {
+    if (!cfg || S < 0 || C <= 0) return gmp::fail(GMP_ERR_ARG, "bn_running_update: bad sizes");
+    if (S == 0) return GMP_OK;
+    if (!seg_ptr || !running_mean || !running_var || !save_mean || !save_rstd) return gmp::fail(GMP_ERR_ARG, "bn_running_update: null pointer");
+    BnArgs a{};
+    a.seg_ptr = seg_ptr; a.seg_group = seg_group; a.S = S; a.C = C;
+    a.running_mean = running_mean; a.running_var = running_var;
+    a.save_mean = (float*)save_mean; a.save_rstd = (float*)save_rstd; a.cfg = *cfg;
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + THREADS - 1) / THREADS), dim3(THREADS), 0, (hipStream_t)stream, a);
+    return gmp::check_launch("bn_running_kernel");
+}
+
 extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr,
                           const int32_t* seg_group, int S, int64_t max_seg_rows, int64_t rows, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var, const float* save_mean,

@@ -3,6 +3,8 @@
 // transcription of gnn_pretraining_amd/engine.py (_forward, _task_head, _backbone_backward): same entry
 // points, same order, same buffers -> bitwise the same result (tests/test_gpu_engine.py).
 #include "../../include/gnnmp_step.h"
+#include <stdlib.h>
+
 #include "gnnmp_internal.h"
 
 namespace {
@@ -24,6 +26,22 @@ hipEvent_t* events() {   // one process drives one engine: a small static pool o
         made = true;
     }
     return ev;
+}
+
+// phase timing (diagnostic, GMP_STEP_TIMING=1): events on the main stream at step start / forward done / heads joined /
+// backward done, read back by gmp_step_phase_ms
+hipEvent_t* phase_events() {
+    static hipEvent_t ev[4];
+    static bool made = false;
+    if (!made) {
+        for (int i = 0; i < 4; ++i) (void)hipEventCreate(&ev[i]);
+        made = true;
+    }
+    return ev;
+}
+bool phase_timing() {
+    static const bool on = getenv("GMP_STEP_TIMING") != nullptr;
+    return on;
 }
 
 gmp_bn_config bn_cfg(const gmp_step_desc& d, bool relu, bool dropout, uint32_t site) {
@@ -233,6 +251,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     const int T = d.num_tasks;
     float* tg = d.task_grads;
 
+    const bool timing = phase_timing();
+    if (timing) (void)hipEventRecord(phase_events()[0], main);
     // ---- CSR builds beside the encoders (they only need the uploaded indices)
     (void)hipEventRecord(ev[0], main);
     (void)hipStreamWaitEvent(aux, ev[0], 0);
@@ -252,8 +272,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     GMP_TRY(gmp_encoder_fwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, d.tiles, d.num_tiles, d.flat,
                             d.num_domains, d.enc_off_w, d.enc_off_b, d.enc_d_in, d.dpad, d.z0, main_));
     gmp_bn_config c = bn_cfg(d, true, true, 1);
-    GMP_TRY(gmp_bn_fwd(d.z0, nullptr, d.seg_ptr, d.seg_dom, d.S, d.max_seg, N, H, d.flat + d.enc_off_gamma0, d.flat + d.enc_off_beta0, d.enc_rm,
-                       d.enc_rv, d.enc_mean, d.enc_rstd, d.h[0], &c, d.bn_ws, d.bn_ws_bytes, main_));
+    // training: the running statistics are brought up to date at the end of the step on the aux stream (see below)
+    const bool defer = d.training != 0;
+    GMP_TRY(gmp_bn_fwd(d.z0, nullptr, d.seg_ptr, d.seg_dom, d.S, d.max_seg, N, H, d.flat + d.enc_off_gamma0, d.flat + d.enc_off_beta0,
+                       defer ? nullptr : d.enc_rm, defer ? nullptr : d.enc_rv, d.enc_mean, d.enc_rstd, d.h[0], &c, d.bn_ws, d.bn_ws_bytes, main_));
     if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {
         const gmp_task_desc& t = d.task[d.nfm_task];
         GMP_TRY(gmp_row_gather(d.h[0], t.idx, nullptr, t.nfm_target, t.num_idx, N, H, main_));
@@ -267,17 +289,29 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_gin_aggregate_fwd(d.h[l], d.csr[0], d.csr[1], d.flat + L.off_eps, L.a, N, H, main_));
         GMP_TRY(gemm(GMP_GEMM_NT, L.a, d.flat + L.off_w1, d.flat + L.off_b1, L.z1, N, 2 * H, H, H, H, 2 * H, false, main_));
         c = bn_cfg(d, true, false, 0);
-        GMP_TRY(gmp_bn_fwd(L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1, L.s1,
-                           L.r1, &c, d.bn_ws, d.bn_ws_bytes, main_));
+        GMP_TRY(gmp_bn_fwd(L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, defer ? nullptr : L.rm1,
+                           defer ? nullptr : L.rv1, L.m1, L.s1, L.r1, &c, d.bn_ws, d.bn_ws_bytes, main_));
         GMP_TRY(gemm(GMP_GEMM_NT, L.r1, d.flat + L.off_w2, d.flat + L.off_b2, L.z2, N, H, 2 * H, 2 * H, 2 * H, H, false, main_));
         c = bn_cfg(d, true, true, 10 + l);
-        GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2,
-                           d.h[l + 1], &c, d.bn_ws, d.bn_ws_bytes, main_));
+        GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, defer ? nullptr : L.rm2,
+                           defer ? nullptr : L.rv2, L.m2, L.s2, d.h[l + 1], &c, d.bn_ws, d.bn_ws_bytes, main_));
     }
 
     // ---- task heads, each on its own stream
     if (hipMemsetAsync(d.gA, 0, (size_t)N * H * sizeof(float), main) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step: memset");
     (void)hipEventRecord(ev[3], main);
+    if (timing) (void)hipEventRecord(phase_events()[1], main);
+    if (defer) {          // running statistics of the 11 BatchNorms: off the critical path, on aux while the heads start
+        (void)hipStreamWaitEvent(aux, ev[3], 0);
+        c = bn_cfg(d, true, false, 0);
+        GMP_TRY(gmp_bn_running_update(d.seg_ptr, d.seg_dom, d.S, H, d.enc_rm, d.enc_rv, d.enc_mean, d.enc_rstd, &c, aux_));
+        for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
+            const gmp_layer_desc& L = d.layer[l];
+            GMP_TRY(gmp_bn_running_update(d.seg_ptr, nullptr, d.S, 2 * H, L.rm1, L.rv1, L.m1, L.s1, &c, aux_));
+            GMP_TRY(gmp_bn_running_update(d.seg_ptr, nullptr, d.S, H, L.rm2, L.rv2, L.m2, L.s2, &c, aux_));
+        }
+        (void)hipEventRecord(ev[NEV - 1], aux);
+    }
     for (int ti = 0; ti < T; ++ti) {
         hipStream_t ts = (hipStream_t)task_streams[ti];
         if (ts != main) (void)hipStreamWaitEvent(ts, ev[3], 0);
@@ -289,6 +323,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         }
     }
     (void)hipStreamWaitEvent(main, ev[2], 0);
+    if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved statistics
+    if (timing) (void)hipEventRecord(phase_events()[2], main);
 
     // ---- stacked backbone backward: per-task parameter gradients from ONE pass.
     // The input-gradient chain (BN bwd -> dgrad GEMM -> BN bwd -> dgrad GEMM -> aggregation bwd) is the critical path;
@@ -343,5 +379,16 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
                                 d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
     }
+    if (timing) (void)hipEventRecord(phase_events()[3], main);
+    return GMP_OK;
+}
+
+extern "C" int gmp_step_phase_ms(float* out3) {
+    if (!out3) return gmp::fail(GMP_ERR_ARG, "step_phase_ms: null pointer");
+    if (!phase_timing()) return gmp::fail(GMP_ERR_UNSUPPORTED, "step_phase_ms: set GMP_STEP_TIMING=1 before the first step");
+    hipEvent_t* e = phase_events();
+    if (hipEventSynchronize(e[3]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_ms: no step recorded");
+    for (int i = 0; i < 3; ++i)
+        if (hipEventElapsedTime(&out3[i], e[i], e[i + 1]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_ms: elapsed");
     return GMP_OK;
 }

@@ -21,6 +21,7 @@ No autograd: forward and backward are explicit kernel sequences over a prealloca
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -40,6 +41,9 @@ from .pretrain.tasks import sample_negative_edges
 H = GNN_HIDDEN_DIM
 NT, NN, TN = 0, 1, 2
 MAXT = 8
+# rough length (us) of each head's kernel chain at the s4 workload, used only to balance heads over the four streams
+HEAD_CHAIN_US = {"node_contrast": 350.0, "link_pred": 330.0, "graph_contrast": 250.0, "node_feat_mask": 130.0, "graph_prop": 100.0,
+                 "domain_adv": 100.0}
 SUPPORTED_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast", "graph_prop", "domain_adv")
 DA_HIDDEN, DA_DROPOUT = 128, 0.5          # heads.py:11-12
 
@@ -232,9 +236,22 @@ class StepEngine:
         self.gB2, self.gW3 = f(R, H), f(R, 2 * H)
         self.rowdot = f(R)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs
-        # the task heads are independent of each other: each runs on its own stream with its own scratch
-        self.task_streams = [torch.cuda.Stream(device=dev) for _ in range(self.T)]
+        # the task heads are independent of each other: each has its own scratch and they share four streams
+        # The runtime multiplexes HIP streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; raising it made the step 2.4x
+        # slower), and a per-task stream layout left three task heads serialised on one queue (profiles/README.md).  So:
+        # exactly four streams -- main, aux and two more -- and the heads are packed onto them by estimated chain length
+        # (longest first onto the least-loaded stream; main and aux are idle while the heads run).
         self.aux_stream = torch.cuda.Stream(device=dev)
+        extra = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        bins = [[0.0, extra[0]], [0.0, extra[1]], [0.0, self.aux_stream], [0.0, None]]      # None = the main stream
+        self.task_streams = [None] * self.T
+        if os.environ.get("GMP_HEAD_LAYOUT") == "per_task":                 # A/B aid: the old one-stream-per-task layout
+            self.task_streams = [torch.cuda.Stream(device=dev) for _ in range(self.T)]
+            bins = []
+        for ti in (sorted(range(self.T), key=lambda i: -HEAD_CHAIN_US.get(self.tasks[i], 100.0)) if bins else []):
+            b = min(bins, key=lambda x: x[0])
+            b[0] += HEAD_CHAIN_US.get(self.tasks[ti], 100.0)
+            self.task_streams[ti] = b[1]
         self.task_gemm_ws = [torch.empty(24 << 20, dtype=torch.uint8, device=dev) for _ in range(self.T)]
         self.task_loss_ws = [torch.empty(self.lib.gmp_loss_workspace_bytes(R * H), dtype=torch.uint8, device=dev) for _ in range(self.T)]
         self._cur_gemm_ws = self.gemm_ws
@@ -807,16 +824,18 @@ class StepEngine:
         ev_fwd = torch.cuda.Event(); ev_fwd.record(main)
         done = []
         for ti, t in enumerate(self.tasks):
-            ts = self.task_streams[ti]
-            ts.wait_event(ev_fwd)
+            ts = main if self.task_streams[ti] is None else self.task_streams[ti]
+            if ts is not main:
+                ts.wait_event(ev_fwd)
             if t == "link_pred":
                 ts.wait_event(p.ev_lpcsr)
             with torch.cuda.stream(ts):
                 self._use_stream(ts)
                 self._cur_gemm_ws, self.loss_ws = self.task_gemm_ws[ti], self.task_loss_ws[ti]
                 self._task_head(p, inp, ti, t, hL, gH, sc, T_)
-                ev = torch.cuda.Event(); ev.record(ts)
-                done.append(ev)
+                if ts is not main:
+                    ev = torch.cuda.Event(); ev.record(ts)
+                    done.append(ev)
         self._use_stream(main)
         self._cur_gemm_ws = self.gemm_ws
         self.loss_ws = self.task_loss_ws[0]
@@ -1166,7 +1185,8 @@ class StepEngine:
                     setattr(td, "lp_tg_" + a, self._TG(ti, full))
                 td.lp_site = 100 + ti
         self._desc = d
-        self._stream_arr = (C.c_void_p * self.T)(*[s.cuda_stream for s in self.task_streams])
+        main_h = torch.cuda.current_stream(self.device).cuda_stream
+        self._stream_arr = (C.c_void_p * self.T)(*[(s.cuda_stream if s is not None else main_h) for s in self.task_streams])
         return d
 
     def _fill_desc(self, p: StepPlan, inp: StepInputs):

@@ -185,6 +185,11 @@ int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, co
                const float* gamma, const float* beta, float* running_mean, float* running_var,
                float* save_mean, float* save_rstd, float* y,
                const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+/* Training-mode gmp_bn_fwd with running_mean == NULL leaves the running statistics alone; this applies that update later
+ * from the saved batch statistics (segments in order, as S successive forward() calls would: bit-identical). */
+int gmp_bn_running_update(const int32_t* seg_ptr, const int32_t* seg_group, int num_segments, int channels,
+                          float* running_mean, float* running_var, const float* save_mean, const float* save_rstd,
+                          const gmp_bn_config* cfg, gmp_stream_t stream);
 /* backward: given g_y, the BN input u = x (+ residual, recomputed on the fly), saved stats.
  *   g_u [rows,C]   gradient w.r.t. the BN input (also the residual's gradient)
  *   g_gamma/g_beta: per GRADIENT group sums (<= 24 groups, one launch); group g covers segments

@@ -118,6 +118,10 @@ size_t gmp_step_desc_size(void);
  * aux: stream for the CSR builds (may equal main). */
 int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* desc, gmp_stream_t main, const gmp_stream_t* task_streams,
                               gmp_stream_t aux);
+/* Diagnostic: with GMP_STEP_TIMING=1 in the environment the call above records events on `main` at step start, forward
+ * done, heads joined and backward done; this waits for the last one and returns the three phase durations in ms
+ * (forward, heads, backward) of the most recent step. */
+int gmp_step_phase_ms(float* out3);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,37 @@
+"""Phase durations of the s4 step on the GPU clock (no profiler): forward / heads / backward (+ optimizer by difference).
+GMP_STEP_TIMING=1 python scripts/diag_step_phases.py [per_task|packed]"""
+import ctypes as C, os, sys, time
+os.environ["GMP_STEP_TIMING"] = "1"
+if len(sys.argv) > 1:
+    os.environ["GMP_HEAD_LAYOUT"] = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+from gnn_pretraining_amd import _lib as L
+from gnn_pretraining_amd.engine import StepEngine
+from gnn_pretraining_amd.models.pretrain_model import PretrainableGNN
+from gnn_pretraining_amd.pretrain import pretrain as PT
+
+dev = torch.device("cuda:0")
+torch.set_num_threads(1)
+model = PretrainableGNN(device=dev, domain_names=PT.PRETRAIN_DOMAINS["s4"], task_names=PT.ACTIVE_TASKS["s4"])
+model.train()
+eng = StepEngine(model, PT.ACTIVE_TASKS["s4"], PT.PRETRAIN_DOMAINS["s4"], dev, seed=0, rng_mode="vectorized")
+pool = B.make_pool(0, dev, eng.dpad)
+gen = torch.Generator().manual_seed(0)
+acc, n = [0.0, 0.0, 0.0], 0
+out = (C.c_float * 3)()
+t_all = 0.0
+for k in range(80):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(pool[k % len(pool)], gen)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    L.check(L.lib().gmp_step_phase_ms(out), "phase")
+    if k >= 20:
+        for i in range(3):
+            acc[i] += out[i]
+        t_all += (t1 - t0) * 1e3
+        n += 1
+print(os.environ.get("GMP_HEAD_LAYOUT", "packed"), "forward %.3f heads %.3f backward %.3f ms | whole synchronous step %.3f ms" % (acc[0] / n, acc[1] / n, acc[2] / n, t_all / n))
