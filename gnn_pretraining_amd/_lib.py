@@ -83,6 +83,8 @@ _SIGS: Dict[str, tuple] = {
     "gmp_nt_xent_workspace_bytes": (sz, [i64, i32]),
     "gmp_nt_xent_fwd": (C.c_int, [p, p, i64, i32, f32, p, p, sz, p]),
     "gmp_nt_xent_bwd": (C.c_int, [p, p, i64, i32, f32, p, p, p, p, sz, p]),
+    "gmp_nt_xent_grouped_workspace_bytes": (sz, [i32, i64, i32]),
+    "gmp_nt_xent_grouped": (C.c_int, [p, p, i32, p, p, i32, f32, p, p, p, p, sz, p]),
     "gmp_dropout_fwd": (C.c_int, [p, p, i64, f32, C.c_uint64, C.c_uint32, p]),
     "gmp_relu_dropout_bwd": (C.c_int, [p, p, p, i64, f32, C.c_uint64, C.c_uint32, p]),
     "gmp_loss_workspace_bytes": (sz, [i64]),

@@ -161,3 +161,190 @@ extern "C" int gmp_nt_xent_bwd(const float* z1, const float* z2, int64_t n, int 
                        (const float*)w.zn, (const float*)w.norm, (const float*)w.gzn, g_scale, n, d, g_z1, g_z2);
     return gmp::check_launch("nt_xent_bwd kernels");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Grouped form: the per-domain NT-Xent problems of one task (tasks.py:192-213 runs them domain by domain) in 7 launches
+// instead of 7 per domain.  Every group gets a zero-padded slot of Rmax = 2 * max_n rows in the workspace, so the three
+// GEMMs are uniform batched problems (gemm_f32 grouped form, blockIdx.z = group); padding rows / columns are zeros and
+// add nothing, so each group's numbers are those of the single-problem entry points above.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int MAXG = 8;
+struct NtxGroups {
+    int G, Rmax, d;
+    int n[MAXG];
+    int64_t off[MAXG];      // first row of the group's [z1; z2] block in z / g_z
+};
+
+struct GWs {
+    float *zn, *norm, *Gm, *gzn, *gzn2, *rowloss;
+};
+
+GWs gcarve(void* ws, int G, int64_t Rmax, int d) {
+    char* p = (char*)ws;
+    GWs w;
+    const size_t rows = (size_t)G * Rmax;
+    w.zn = (float*)p; p += al(rows * d * 4);
+    w.norm = (float*)p; p += al(rows * 4);
+    w.Gm = (float*)p; p += al(rows * Rmax * 4);
+    w.gzn = (float*)p; p += al(rows * d * 4);
+    w.gzn2 = (float*)p; p += al(rows * d * 4);
+    w.rowloss = (float*)p;
+    return w;
+}
+
+// one wave per padded row
+__global__ __launch_bounds__(THREADS) void normalize_grouped_kernel(const float* __restrict__ z, NtxGroups g, float* __restrict__ zn,
+                                                                    float* __restrict__ norm) {
+    const int lane = threadIdx.x % 64;
+    const int64_t pr = ((int64_t)blockIdx.x * THREADS + threadIdx.x) / 64;
+    if (pr >= (int64_t)g.G * g.Rmax) return;
+    const int grp = (int)(pr / g.Rmax), i = (int)(pr % g.Rmax);
+    float* dst = zn + pr * g.d;
+    if (i >= 2 * g.n[grp]) {
+        for (int c = lane; c < g.d; c += 64) dst[c] = 0.f;
+        if (lane == 0) norm[pr] = 1.f;
+        return;
+    }
+    const float* src = z + (g.off[grp] + i) * g.d;
+    float s = 0.f;
+    for (int c = lane; c < g.d; c += 64) s += src[c] * src[c];
+    s = gmp::wave_sum(s);
+    const float nr = fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < g.d; c += 64) dst[c] = src[c] / nr;
+    if (lane == 0) norm[pr] = nr;
+}
+
+// block (i, grp): row i of group grp, exactly row_loss_kernel on the group's R x R corner; padding -> 0
+__global__ __launch_bounds__(THREADS) void row_loss_grouped_kernel(float* __restrict__ Gm, NtxGroups g, float* __restrict__ rowloss) {
+    __shared__ float sh[THREADS / 64];
+    const int grp = blockIdx.y;
+    const int64_t i = blockIdx.x, n = g.n[grp], R = 2 * n, Rm = g.Rmax;
+    float* row = Gm + ((int64_t)grp * Rm + i) * Rm;
+    if (i >= R) {
+        for (int64_t j = threadIdx.x; j < Rm; j += THREADS) row[j] = 0.f;
+        if (threadIdx.x == 0) rowloss[(int64_t)grp * Rm + i] = 0.f;
+        return;
+    }
+    const int64_t pos = i < n ? i + n : i - n;
+    float m = -INFINITY;
+    for (int64_t j = threadIdx.x; j < R; j += THREADS)
+        if (j != i) m = fmaxf(m, row[j]);
+    m = block_reduce(m, sh, true);
+    float s = 0.f;
+    for (int64_t j = threadIdx.x; j < R; j += THREADS)
+        if (j != i) s += expf(row[j] - m);
+    s = block_reduce(s, sh, false);
+    const float lse = m + logf(s);
+    const float sp = row[pos];
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < Rm; j += THREADS) {
+        float p = 0.f;
+        if (j < R) {
+            p = j == i ? 0.f : expf(row[j] - lse);
+            if (j == pos) p -= 1.f;
+        }
+        row[j] = p;
+    }
+    if (threadIdx.x == 0) rowloss[(int64_t)grp * Rm + i] = lse - sp;
+}
+
+// one block: per-group loss sums (same tree as sum_rows_kernel over the group's R rows) and their total in group order
+__global__ __launch_bounds__(THREADS) void loss_sums_grouped_kernel(const float* __restrict__ rowloss, NtxGroups g, float* __restrict__ sums,
+                                                                    float* __restrict__ total) {
+    __shared__ float sh[THREADS];
+    float tot = 0.f;
+    for (int grp = 0; grp < g.G; ++grp) {
+        const int64_t R = 2 * (int64_t)g.n[grp];
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < R; i += THREADS) s += rowloss[(int64_t)grp * g.Rmax + i];
+        __syncthreads();
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = THREADS / 2; d > 0; d >>= 1) {
+            if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (sums) sums[grp] = sh[0];
+            tot += sh[0];
+        }
+    }
+    if (threadIdx.x == 0 && total) total[0] = tot;
+}
+
+__global__ __launch_bounds__(THREADS) void normalize_bwd_grouped_kernel(const float* __restrict__ zn, const float* __restrict__ norm,
+                                                                        const float* __restrict__ gzn, const float* __restrict__ gzn2,
+                                                                        const float* __restrict__ g_scale, NtxGroups g,
+                                                                        float* __restrict__ g_z) {
+    const int lane = threadIdx.x % 64;
+    const int64_t pr = ((int64_t)blockIdx.x * THREADS + threadIdx.x) / 64;
+    if (pr >= (int64_t)g.G * g.Rmax) return;
+    const int grp = (int)(pr / g.Rmax), i = (int)(pr % g.Rmax);
+    if (i >= 2 * g.n[grp]) return;
+    const int d = g.d;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) dot += zn[pr * d + c] * (gzn[pr * d + c] + gzn2[pr * d + c]);
+    dot = gmp::wave_sum(dot);
+    const float nr = norm[pr], gs = g_scale[0];
+    if (nr <= 1e-12f) dot = 0.f;
+    float* dst = g_z + (g.off[grp] + i) * d;
+    for (int c = lane; c < d; c += 64) dst[c] = gs * ((gzn[pr * d + c] + gzn2[pr * d + c]) - zn[pr * d + c] * dot) / nr;
+}
+
+}  // namespace
+
+extern "C" size_t gmp_nt_xent_grouped_workspace_bytes(int groups, int64_t max_n, int d) {
+    if (groups < 1 || max_n < 1 || d < 1) return 0;
+    const size_t Rm = (2 * (size_t)max_n + 3) / 4 * 4, rows = (size_t)groups * Rm;     // slot height, a multiple of 4 (vector loads)
+    return 3 * al(rows * d * 4) + 2 * al(rows * 4) + al(rows * Rm * 4) + 256;
+}
+
+extern "C" int gmp_nt_xent_grouped(const float* z, float* g_z, int groups, const int32_t* n_host, const int64_t* row_off_host, int d,
+                                   float T, const float* g_scale, float* loss_sums, float* loss_total, void* ws, size_t ws_bytes,
+                                   gmp_stream_t stream) {
+    if (groups < 1 || groups > MAXG || !n_host || !row_off_host) return gmp::fail(GMP_ERR_ARG, "nt_xent_grouped: groups=%d (max %d)", groups, MAXG);
+    if (d < 1 || d % 4) return gmp::fail(GMP_ERR_ARG, "nt_xent_grouped: dim %d must be a positive multiple of 4", d);
+    if (!(T > 0.f)) return gmp::fail(GMP_ERR_ARG, "nt_xent_grouped: temperature %f", T);
+    if (!z || !g_z || !g_scale || !ws || (!loss_sums && !loss_total)) return gmp::fail(GMP_ERR_ARG, "nt_xent_grouped: null pointer");
+    NtxGroups g{};
+    g.G = groups; g.d = d;
+    int64_t max_n = 0;
+    for (int i = 0; i < groups; ++i) {
+        if (n_host[i] < 0 || n_host[i] > 8192 || row_off_host[i] < 0) return gmp::fail(GMP_ERR_ARG, "nt_xent_grouped: group %d: n=%d", i, n_host[i]);
+        g.n[i] = n_host[i];
+        g.off[i] = row_off_host[i];
+        if (n_host[i] > max_n) max_n = n_host[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (max_n == 0) {                                    // nothing to contrast anywhere: zero loss, no gradient rows
+        if (loss_sums && hipMemsetAsync(loss_sums, 0, groups * sizeof(float), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "nt_xent_grouped: memset");
+        if (loss_total && hipMemsetAsync(loss_total, 0, sizeof(float), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "nt_xent_grouped: memset");
+        return GMP_OK;
+    }
+    if (ws_bytes < gmp_nt_xent_grouped_workspace_bytes(groups, max_n, d)) return gmp::fail(GMP_ERR_WORKSPACE, "nt_xent_grouped: workspace");
+    const int64_t Rm = (2 * max_n + 3) / 4 * 4;
+    g.Rmax = (int)Rm;
+    GWs w = gcarve(ws, groups, Rm, d);
+    const int64_t prow = (int64_t)groups * Rm;
+    int32_t rows[MAXG + 1];
+    int64_t off_zn[MAXG];
+    for (int i = 0; i <= groups; ++i) rows[i] = (int32_t)(i * Rm);
+    for (int i = 0; i < groups; ++i) off_zn[i] = (int64_t)i * Rm * d;
+    const unsigned wave_blocks = (unsigned)((prow * 64 + THREADS - 1) / THREADS);
+    hipLaunchKernelGGL(normalize_grouped_kernel, dim3(wave_blocks), dim3(THREADS), 0, st, z, g, w.zn, w.norm);
+    // sim_g = zn_g zn_g^T / T
+    if (int rc = gmp_gemm_f32_grouped(GMP_GEMM_NT, w.zn, w.zn, nullptr, w.Gm, groups, rows, off_zn, nullptr, nullptr, nullptr, nullptr, 0, Rm, d,
+                                      d, d, Rm, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
+    hipLaunchKernelGGL(row_loss_grouped_kernel, dim3((unsigned)Rm, groups), dim3(THREADS), 0, st, w.Gm, g, w.rowloss);
+    hipLaunchKernelGGL(loss_sums_grouped_kernel, dim3(1), dim3(THREADS), 0, st, (const float*)w.rowloss, g, loss_sums, loss_total);
+    // d loss / d zn = (G + G^T) zn / T, the two halves into gzn / gzn2
+    if (int rc = gmp_gemm_f32_grouped(GMP_GEMM_NN, w.Gm, w.zn, nullptr, w.gzn, groups, rows, off_zn, nullptr, nullptr, nullptr, nullptr, 0, d, Rm,
+                                      Rm, d, d, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
+    if (int rc = gmp_gemm_f32_grouped(GMP_GEMM_TN, w.Gm, w.zn, nullptr, w.gzn2, groups, rows, nullptr, nullptr, off_zn, nullptr, nullptr, Rm, d, 0,
+                                      Rm, d, d, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
+    hipLaunchKernelGGL(normalize_bwd_grouped_kernel, dim3(wave_blocks), dim3(THREADS), 0, st, (const float*)w.zn, (const float*)w.norm,
+                       (const float*)w.gzn, (const float*)w.gzn2, g_scale, g, g_z);
+    return gmp::check_launch("nt_xent_grouped kernels");
+}

@@ -100,19 +100,10 @@ int mlp2_bwd(const gmp_step_desc& d, const gmp_task_desc& t, float* d1, gmp_stre
 }
 
 int nt_xent_domains(const gmp_step_desc& d, const gmp_task_desc& t, float* z, float* gz, gmp_stream_t st) {
-    const gmp_mlp2& m = t.mlp;
-    for (int di = 0; di < d.num_domains; ++di) {
-        const int n = t.ntx_n[di];
-        if (n == 0) continue;
-        float* z1 = z + (int64_t)128 * m.rows[di];
-        float* z2 = z1 + (int64_t)128 * n;
-        GMP_TRY(gmp_nt_xent_fwd(z1, z2, n, 128, t.temperature, t.ntx_sums + di, t.ntx_ws[di], t.ntx_ws_bytes[di], st));
-        float* g1 = gz + (int64_t)128 * m.rows[di];
-        GMP_TRY(gmp_nt_xent_bwd(z1, z2, n, 128, t.temperature, t.g_scale, g1, g1 + (int64_t)128 * n, t.ntx_ws[di], t.ntx_ws_bytes[di], st));
-    }
-    const int32_t rows[2] = {0, d.num_domains};
-    const int64_t off[1] = {0};
-    return gmp_group_sum_1d(t.ntx_sums, 1, rows, off, t.loss_sum, st);
+    int64_t off[GMP_STEP_MAX_DOMAINS];
+    for (int di = 0; di < d.num_domains; ++di) off[di] = t.mlp.rows[di];
+    return gmp_nt_xent_grouped(z, gz, d.num_domains, t.ntx_n, off, 128, t.temperature, t.g_scale, t.ntx_sums, t.loss_sum, t.ntx_ws[0],
+                               t.ntx_ws_bytes[0], st);
 }
 
 int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
@@ -312,16 +303,19 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         }
         (void)hipEventRecord(ev[NEV - 1], aux);
     }
-    for (int ti = 0; ti < T; ++ti) {
-        hipStream_t ts = (hipStream_t)task_streams[ti];
-        if (ts != main) (void)hipStreamWaitEvent(ts, ev[3], 0);
-        if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
-        GMP_TRY(task_head(d, ti, task_streams[ti]));
-        if (ts != main) {
-            (void)hipEventRecord(ev[4 + ti], ts);
-            (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
+    // heads on other streams first (their chains are the long ones: they start while main is still being fed), the ones packed
+    // onto main last; main joins the other streams only after everything is enqueued
+    for (int pass = 0; pass < 2; ++pass)
+        for (int ti = 0; ti < T; ++ti) {
+            hipStream_t ts = (hipStream_t)task_streams[ti];
+            if ((ts == main) != (pass == 1)) continue;
+            if (ts != main) (void)hipStreamWaitEvent(ts, ev[3], 0);
+            if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
+            GMP_TRY(task_head(d, ti, task_streams[ti]));
+            if (ts != main) (void)hipEventRecord(ev[4 + ti], ts);
         }
-    }
+    for (int ti = 0; ti < T; ++ti)
+        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
     (void)hipStreamWaitEvent(main, ev[2], 0);
     if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved statistics
     if (timing) (void)hipEventRecord(phase_events()[2], main);

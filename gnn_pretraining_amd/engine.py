@@ -281,7 +281,7 @@ class StepEngine:
         self.lp_y2, self.lp_p, self.lp_lab, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)
         self.gp_y2 = f(1024, GRAPH_PROPERTY_DIM)
         self.gp_g2 = f(1024, GRAPH_PROPERTY_DIM)
-        self.ntx_ws = [torch.empty(self.lib.gmp_nt_xent_workspace_bytes(2048, 128), dtype=torch.uint8, device=dev) for _ in range(2 * self.D)]
+        self.ntx_ws = [torch.empty(self.lib.gmp_nt_xent_grouped_workspace_bytes(self.D, 512, 128), dtype=torch.uint8, device=dev) for _ in range(2 * self.D)]
         self.scal = torch.zeros(64, device=dev)              # device scalars: 1/size per task, NT-Xent losses ...
         # packed per-step index uploads (pinned staging)
         self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536, 4 * self.max_edges + 8 * R
@@ -823,7 +823,9 @@ class StepEngine:
         main = torch.cuda.current_stream(self.device)
         ev_fwd = torch.cuda.Event(); ev_fwd.record(main)
         done = []
-        for ti, t in enumerate(self.tasks):
+        order = [ti for ti in range(self.T) if self.task_streams[ti] is not None] + [ti for ti in range(self.T) if self.task_streams[ti] is None]
+        for ti in order:                                     # heads on other streams first, the ones packed onto main last
+            t = self.tasks[ti]
             ts = main if self.task_streams[ti] is None else self.task_streams[ti]
             if ts is not main:
                 ts.wait_event(ev_fwd)
@@ -957,19 +959,16 @@ class StepEngine:
         their total in the task's loss slot."""
         lib, st = self.lib, self._st()
         sc = self.scal.data_ptr()
-        for di, n in enumerate(ns):
-            if n == 0:
-                continue
-            z1 = z.data_ptr() + 4 * 128 * rows[di]
-            z2 = z1 + 4 * 128 * n
-            ws = self.ntx_ws[slot0 + di]
-            need = lib.gmp_nt_xent_workspace_bytes(n, 128)
-            if need > ws.numel():
-                self.ntx_ws[slot0 + di] = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self._chk(lib.gmp_nt_xent_fwd(z1, z2, n, 128, temperature, sc + 4 * (16 + slot0 + di), ws.data_ptr(), ws.numel(), st), "nt_xent")
-            g1 = gz.data_ptr() + 4 * 128 * rows[di]
-            self._chk(lib.gmp_nt_xent_bwd(z1, z2, n, 128, temperature, gs, g1, g1 + 4 * 128 * n, ws.data_ptr(), ws.numel(), st), "nt_xent bwd")
-        self._chk(lib.gmp_group_sum_1d(sc + 4 * (16 + slot0), 1, _i32([0, len(ns)]), _i64([0]), ls, st), "nt_xent total")
+        ws = self._ntx_workspace(slot0, ns)
+        self._chk(lib.gmp_nt_xent_grouped(z.data_ptr(), gz.data_ptr(), len(ns), _i32(list(ns)), _i64([int(r) for r in rows[:len(ns)]]), 128,
+                                          temperature, gs, sc + 4 * (16 + slot0), ls, ws.data_ptr(), ws.numel(), st), "nt_xent grouped")
+
+    def _ntx_workspace(self, slot0: int, ns) -> Tensor:
+        """One grouped workspace per contrastive task (slot0 = 0 node level, D graph level), grown on demand."""
+        need = self.lib.gmp_nt_xent_grouped_workspace_bytes(len(ns), max(max(ns), 1), 128)
+        if need > self.ntx_ws[slot0].numel():
+            self.ntx_ws[slot0] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.ntx_ws[slot0]
 
     def _backbone_backward(self, p: StepPlan, inp: StepInputs) -> None:
         lib, st, N, D, P, TG, T = self.lib, self._st(), p.N, self.domains, self._P, self._TG, self.T
@@ -1231,11 +1230,8 @@ class StepEngine:
                 td.temperature = T_
                 for di, n in enumerate(ns):
                     td.ntx_n[di] = n
-                    if n:
-                        need = self.lib.gmp_nt_xent_workspace_bytes(n, 128)
-                        if need > self.ntx_ws[slot0 + di].numel():
-                            self.ntx_ws[slot0 + di] = torch.empty(need, dtype=torch.uint8, device=self.device)
-                    td.ntx_ws[di], td.ntx_ws_bytes[di] = self.ntx_ws[slot0 + di].data_ptr(), self.ntx_ws[slot0 + di].numel()
+                ws = self._ntx_workspace(slot0, ns)
+                td.ntx_ws[0], td.ntx_ws_bytes[0] = ws.data_ptr(), ws.numel()
             if t == "graph_contrast":
                 td.pool_ptr, td.pool_gid, td.pool_B, td.pool_r0, td.pool_M = p.d32["gc_ptr"], p.d64["gc_gid"], p.gc_B, p.gc_r0, p.gc_M
             if t == "graph_prop":

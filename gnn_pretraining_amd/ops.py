@@ -327,6 +327,23 @@ def hard_negative_topk(emb: Tensor, existing_edges: Tensor, k: int, return_score
     return res if len(res) > 1 else out
 
 
+def nt_xent_grouped(z: Tensor, ns, row_offsets, temperature: float, g_scale: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """Several NT-Xent problems in one call: group g's rows [z1; z2] (2*ns[g] of them) start at row_offsets[g] of z.
+    Returns (g_z [same shape as z; rows outside every group untouched = 0], loss_sums [G], loss_total [1])."""
+    _need(z, torch.float32, "z", 2); _need(g_scale, torch.float32, "g_scale")
+    G, d = len(ns), z.size(1)
+    l = L.lib()
+    ws = _ws(l.gmp_nt_xent_grouped_workspace_bytes(G, max(max(ns), 1), d), z.device)
+    gz = torch.zeros_like(z)
+    sums = torch.empty(G, dtype=torch.float32, device=z.device)
+    total = torch.empty(1, dtype=torch.float32, device=z.device)
+    n_arr = (C.c_int32 * G)(*[int(n) for n in ns])
+    o_arr = (C.c_int64 * G)(*[int(o) for o in row_offsets])
+    L.check(l.gmp_nt_xent_grouped(_ptr(z), _ptr(gz), G, n_arr, o_arr, d, float(temperature), _ptr(g_scale), _ptr(sums), _ptr(total),
+                                  _ptr(ws), ws.numel(), _stream(z)), "gmp_nt_xent_grouped")
+    return gz, sums, total
+
+
 def dropout_fwd(x: Tensor, p: float, seed: int, stream_id: int) -> Tensor:
     _need(x, torch.float32, "x")
     if x.numel() % 4:

@@ -321,3 +321,33 @@ def test_nt_xent(n, d, T):
     close(loss, want.reshape(1), what="nt_xent loss")
     g1, g2 = ops.nt_xent_bwd(z1.to(DEV), z2.to(DEV), T, torch.tensor([0.25], device=DEV), ws)
     close(g1, a.grad, rtol=2e-4, what="nt_xent g_z1"); close(g2, b.grad, rtol=2e-4, what="nt_xent g_z2")
+
+
+@pytest.mark.parametrize("ns", [[8, 8, 8, 8], [201, 0, 37, 150], [1, 5], [0, 0, 0]])
+def test_nt_xent_grouped_equals_the_single_problem_calls(ns):
+    """the per-domain problems of a contrastive task in one call: per group the loss sum and the gradient are those of
+    gmp_nt_xent_fwd/_bwd on that group alone (zero padding adds nothing) -- held bit-exact"""
+    gen = torch.Generator().manual_seed(sum(ns) + len(ns))
+    d, T = 128, 0.37
+    offs, rows = [], 3                                   # leading rows that belong to no group
+    for n in ns:
+        offs.append(rows)
+        rows += 2 * n + 1                                # and a stray row between groups
+    z = torch.randn(rows, d, generator=gen).to(DEV)
+    gs = torch.tensor([0.125], device=DEV)
+    gz, sums, total = ops.nt_xent_grouped(z, ns, offs, T, gs)
+    want_total = 0.0
+    touched = torch.zeros(rows, dtype=torch.bool)
+    for g, n in enumerate(ns):
+        if n == 0:
+            assert float(sums[g]) == 0.0
+            continue
+        z1, z2 = z[offs[g]:offs[g] + n].contiguous(), z[offs[g] + n:offs[g] + 2 * n].contiguous()
+        loss, ws = ops.nt_xent_fwd(z1, z2, T)
+        g1, g2 = ops.nt_xent_bwd(z1, z2, T, gs, ws)
+        assert torch.equal(sums[g:g + 1], loss), f"group {g} loss"
+        assert torch.equal(gz[offs[g]:offs[g] + n], g1) and torch.equal(gz[offs[g] + n:offs[g] + 2 * n], g2), f"group {g} gradient"
+        want_total += float(loss)
+        touched[offs[g]:offs[g] + 2 * n] = True
+    assert abs(float(total) - want_total) <= 1e-5 * max(abs(want_total), 1.0)
+    assert float(gz[~touched.to(DEV)].abs().max() if (~touched).any() else 0.0) == 0.0
