@@ -284,6 +284,21 @@ __device__ __forceinline__ float4 bwd_input(const BnArgs& a, float4 gaff, float4
                        k.z * (gaff.z - s1.z * inv_n - xhat.z * s2.z * inv_n), k.w * (gaff.w - s1.w * inv_n - xhat.w * s2.w * inv_n));
 }
 
+// gate (ReLU mask x dropout scale) of one float4 from its normalised value: what bn_apply derives, without the output
+__device__ __forceinline__ float4 gate_of(const BnArgs& a, float4 xh, float4 gam, float4 bet, int64_t elem_quad) {
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.cfg.relu) {
+        const float4 y = make_float4(fmaf(gam.x, xh.x, bet.x), fmaf(gam.y, xh.y, bet.y), fmaf(gam.z, xh.z, bet.z), fmaf(gam.w, xh.w, bet.w));
+        g = make_float4(y.x > 0.f, y.y > 0.f, y.z > 0.f, y.w > 0.f);
+    }
+    if (a.cfg.dropout_p > 0.f)
+        g = mul4(g, gmp::dropout_scale4(a.cfg.seed, a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p, 1.f / (1.f - a.cfg.dropout_p)));
+    return g;
+}
+
+// Register-resident like the forward, but only the normalised inputs stay in registers (RPT float4): the upstream gradient is
+// read twice (second time out of L2) and the gate is recomputed.  Keeping both operands resident needed 256 VGPRs at
+// RPT = 16 -- one wave per SIMD, nothing to hide a load behind -- and made this the slowest kernel of the backward chain.
 template <int RPT>
 __global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
     __shared__ float4 sh[SRL][SCQ];
@@ -298,16 +313,18 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
     const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
-    float4 xh[RPT], ga[RPT];
+    float4 xh[RPT];
     float4 a1 = zero4(), a2 = zero4();
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = r0 + rl + i * SRL;
-        xh[i] = zero4(); ga[i] = zero4();
+        xh[i] = zero4();
         if (r < r1) {
-            bwd_elem(a, (int64_t)r * a.C + c, mean, rstd, gam, bet, &ga[i], &xh[i]);
-            a1 = add4(a1, ga[i]);
-            a2 = add4(a2, mul4(ga[i], xh[i]));
+            const int64_t off = (int64_t)r * a.C + c;
+            xh[i] = mul4(sub4(load_u(a, off), mean), rstd);
+            const float4 ga = mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
+            a1 = add4(a1, ga);
+            a2 = add4(a2, mul4(ga, xh[i]));
         }
     }
     const float4 s1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
@@ -317,7 +334,11 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = r0 + rl + i * SRL;
-        if (r < r1) st4(a.y + (int64_t)r * a.C + c, bwd_input(a, ga[i], xh[i], s1, s2, gam, rstd, inv_n));
+        if (r < r1) {
+            const int64_t off = (int64_t)r * a.C + c;
+            const float4 ga = mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
+            st4(a.y + off, bwd_input(a, ga, xh[i], s1, s2, gam, rstd, inv_n));
+        }
     }
 }
 
@@ -532,4 +553,26 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
                            g_gamma, g_beta);
     }
     return gmp::check_launch("bn_bwd kernels");
+}
+
+// The parameter-gradient half of gmp_bn_bwd on its own: a gmp_bn_bwd call with num_groups = 0 leaves the per-segment sums
+// (sum g, sum g*xhat) at the start of its workspace; this reduces them per group -- same kernel, same order, bit-identical --
+// on any stream, so the caller can keep it off the input-gradient chain.
+extern "C" int gmp_bn_param_grads(const void* bwd_workspace, int S, int C, float* g_gamma, float* g_beta,
+                                  const int32_t* grp_seg_ptr_host, const int64_t* grp_off_gamma_host,
+                                  const int64_t* grp_off_beta_host, int G, gmp_stream_t stream) {
+    if (G < 1 || G > GMP_MAX_GROUPS || !grp_seg_ptr_host || !g_gamma || !g_beta || !bwd_workspace || C <= 0 || S < 0)
+        return gmp::fail(GMP_ERR_ARG, "bn_param_grads: bad argument (G=%d, max %d)", G, GMP_MAX_GROUPS);
+    BnGroups grp{};
+    grp.n = G;
+    for (int g = 0; g <= G; ++g) grp.seg[g] = grp_seg_ptr_host[g];
+    for (int g = 0; g < G; ++g) {
+        if (grp.seg[g] < 0 || grp.seg[g] > grp.seg[g + 1] || grp.seg[g + 1] > S)
+            return gmp::fail(GMP_ERR_ARG, "bn_param_grads: group %d covers segments [%d,%d) of %d", g, grp.seg[g], grp.seg[g + 1], S);
+        grp.off_gamma[g] = grp_off_gamma_host ? grp_off_gamma_host[g] : (int64_t)g * C;
+        grp.off_beta[g] = grp_off_beta_host ? grp_off_beta_host[g] : (int64_t)g * C;
+    }
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + THREADS - 1) / THREADS, G), dim3(THREADS), 0, (hipStream_t)stream,
+                       (const float*)bwd_workspace, C, grp, g_gamma, g_beta);
+    return gmp::check_launch("bn_param_grad_kernel");
 }

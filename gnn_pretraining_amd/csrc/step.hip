@@ -325,6 +325,13 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // the weight-gradient GEMMs only feed task_grads, so they run beside it on the aux stream.  gB/gB2 and gW2/gW3
     // alternate per layer so a layer's weight-gradient GEMM can still read its operand while the next layer writes.
     hipEvent_t* evl = ev + 4 + GMP_STEP_MAX_TASKS;       // per layer: [0] g_u ready, [1] dW2 done, [2] g_z1 ready, [3] dW1 done
+    // BatchNorm gamma/beta gradients also only feed task_grads: each BN backward leaves its per-segment sums in its own slice
+    // of bn_ws and the reduction per task runs on aux next to the weight-gradient GEMM (falls back to inline when the
+    // workspace cannot hold a slice per BatchNorm)
+    const size_t bn_slice = gmp_bn_workspace_bytes(N, 2 * H, d.S, d.max_seg);
+    const bool split_pg = d.bn_ws_bytes >= bn_slice * (2 * GMP_STEP_LAYERS + 1);
+    auto slice = [&](int i) { return (void*)((char*)d.bn_ws + (split_pg ? bn_slice * (size_t)i : 0)); };
+    const size_t slice_bytes = split_pg ? bn_slice : d.bn_ws_bytes;
     float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
@@ -334,9 +341,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 1], 0);   // dW2 of layer l+2 has read this gu copy
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
-                           tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+                           tg, tg, d.task_seg, L.tg_g2, L.tg_be2, split_pg ? 0 : T, &c, slice(1 + 2 * l), slice_bytes, main_));
         (void)hipEventRecord(e[0], main);
         (void)hipStreamWaitEvent(aux, e[0], 0);
+        if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
         (void)hipEventRecord(e[1], aux);
@@ -344,9 +352,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
-                           L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, &c, d.bn_ws, d.bn_ws_bytes, main_));
+                           L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
         (void)hipEventRecord(e[2], main);
         (void)hipStreamWaitEvent(aux, e[2], 0);
+        if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
         (void)hipEventRecord(e[3], aux);

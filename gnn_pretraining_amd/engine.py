@@ -255,7 +255,9 @@ class StepEngine:
         self.task_gemm_ws = [torch.empty(24 << 20, dtype=torch.uint8, device=dev) for _ in range(self.T)]
         self.task_loss_ws = [torch.empty(self.lib.gmp_loss_workspace_bytes(R * H), dtype=torch.uint8, device=dev) for _ in range(self.T)]
         self._cur_gemm_ws = self.gemm_ws
-        self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(R, 2 * H, self.S_MAX, 512), dtype=torch.uint8, device=dev)
+        # one slice per BatchNorm (11) + spare, each large enough for the long-segment regime (segments up to R rows): the
+        # native executor keeps every BN backward's per-segment sums until the aux stream has reduced them per task
+        self.bn_ws = torch.empty(12 * self.lib.gmp_bn_workspace_bytes(R, 2 * H, self.S_MAX, R), dtype=torch.uint8, device=dev)
         self.csr_ws = torch.empty(self.lib.gmp_csr_build_workspace_bytes(R, self.max_edges), dtype=torch.uint8, device=dev)
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
         self.csr = [i32(R + 1), i32(self.max_edges), i32(self.max_edges), i32(R + 1), i32(self.max_edges), i32(self.max_edges)]

@@ -204,6 +204,12 @@ int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const in
                const int64_t* grp_off_gamma_host, const int64_t* grp_off_beta_host, int num_groups,
                const gmp_bn_config* cfg, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 
+/* gmp_bn_bwd with num_groups = 0 leaves the per-segment sums at the start of its workspace; this turns them into the per-group
+ * g_gamma / g_beta later, on any stream (bit-identical to passing the groups to gmp_bn_bwd). */
+int gmp_bn_param_grads(const void* bwd_workspace, int num_segments, int channels, float* g_gamma, float* g_beta,
+                       const int32_t* grp_seg_ptr_host, const int64_t* grp_off_gamma_host, const int64_t* grp_off_beta_host,
+                       int num_groups, gmp_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Link-prediction edge features (the per-edge MLP input, heads.py:58-66):
  *   feat[k,:] = [ hs+hd | hs*hd | |hs-hd| ],  hs = h[edges[0,k]], hd = h[edges[1,k]]
