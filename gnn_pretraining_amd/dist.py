@@ -72,3 +72,37 @@ class FlatGradSync:
 
     def average_model_grads_(self, model: torch.nn.Module) -> None:
         self.average_([p.grad for _, p in model.named_parameters() if p.grad is not None])
+
+
+class PackedGradSync:
+    """The same exchange for the stacked engine, where every slice lives in ONE device buffer (the [tasks, params] per-task
+    gradient matrix): a table of (offset, length) slices is fixed at construction, one kernel packs them into the message,
+    one all-reduce, one kernel writes the mean back (libgnnmp gmp_segments_pack / _unpack) -- instead of torch.cat plus a
+    copy_ per slice.  Offsets / lengths in floats, multiples of 4 (the engine aligns every tensor to 4 floats)."""
+
+    def __init__(self, base: Tensor, slices) -> None:
+        from . import _lib as L
+        self._L = L
+        self.base = base
+        offs = [int(o) for o, _ in slices]
+        lens = [int(n) for _, n in slices]
+        if any(o % 4 or n % 4 for o, n in zip(offs, lens)):
+            raise ValueError("PackedGradSync: slice offsets and lengths must be multiples of 4 floats")
+        pre = [0]
+        for n in lens:
+            pre.append(pre[-1] + n)
+        self.n, self.total = len(offs), pre[-1]
+        self.table = torch.tensor(offs + pre, dtype=torch.int64, device=base.device)
+        self.packed = torch.empty(self.total, dtype=torch.float32, device=base.device)
+
+    def average_(self) -> None:
+        w = world_size()
+        if w == 1 or self.total == 0:
+            return
+        L = self._L
+        st = torch.cuda.current_stream(self.base.device).cuda_stream
+        L.check(L.lib().gmp_segments_pack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total, st),
+                "gmp_segments_pack")
+        dist.all_reduce(self.packed, op=dist.ReduceOp.SUM)
+        L.check(L.lib().gmp_segments_unpack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total,
+                                            1.0 / w, st), "gmp_segments_unpack")

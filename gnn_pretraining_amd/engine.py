@@ -128,6 +128,7 @@ class StepEngine:
         self.seed, self.step_count = seed, 0
         self.shuffle_rng = shuffle_rng
         self.grad_sync = grad_sync
+        self._packed_sync = None
         self.temperature = 0.5
         self.da_dropout = DA_DROPOUT
         self.grl_lambda = 0.0              # gradient-reversal strength of the domain-adversarial task (GRLScheduler)
@@ -1074,12 +1075,15 @@ class StepEngine:
     def _sync_task_grads(self) -> None:
         """Data parallel: average the per-task gradients over ranks BEFORE PCGrad -- shared tensors once per task,
         every head once (only its own task's row is meaningful) -- in one flat all-reduce."""
-        parts = [self.task_grads[t, :self.P_shared] for t in range(self.T)]
-        for k, n in enumerate(self.names):
-            if n.startswith("heads."):
-                t = int(np.argmax(self.has_static[k]))
-                parts.append(self.task_grads[t, self.off[n]:self.off[n] + self.numel[n]])
-        self.grad_sync.average_(parts)
+        if self._packed_sync is None:
+            from .dist import PackedGradSync
+            slices = [(t * self.P, self.P_shared) for t in range(self.T)]
+            for k, n in enumerate(self.names):
+                if n.startswith("heads."):
+                    t = int(np.argmax(self.has_static[k]))
+                    slices.append((t * self.P + self.off[n], -(-self.numel[n] // 4) * 4))       # tensors are 4-float aligned
+            self._packed_sync = PackedGradSync(self.task_grads.view(-1), slices)
+        self._packed_sync.average_()
 
     # ---- reporting (the only host syncs, and only on request) ---------------------------------------
     def losses(self) -> Dict[str, float]:

@@ -309,6 +309,16 @@ int gmp_hard_negative_topk(const float* emb, int64_t n, int64_t dim, const int64
                            void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Pack / unpack a fixed list of slices of one buffer into one contiguous message (the data-parallel exchange of per-task
+ * gradients: only the (task, tensor) pairs that carry a gradient travel).  table_dev: device int64 [2n+1] = n source offsets
+ * (floats into base) followed by the n+1 exclusive prefix sums of the slice lengths; offsets and lengths are multiples of 4;
+ * n <= 256; total = prefix[n].  unpack multiplies by `scale` (1 / world size).
+ * ------------------------------------------------------------------------- */
+int gmp_segments_pack(const float* base, float* packed, const int64_t* table_dev, int n, int64_t total, gmp_stream_t stream);
+int gmp_segments_unpack(float* base, const float* packed, const int64_t* table_dev, int n, int64_t total, float scale,
+                        gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one
  * launch.  Features of all domains sit padded to `dpad` (<= 64) columns in x_all [R, dpad]; stacked row
  * r reads x_all[src_row[r]]; segment s belongs to domain seg_dom[s] (weights at params + w_off_host[d],

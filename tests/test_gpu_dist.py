@@ -1,0 +1,80 @@
+"""Data-parallel exchange of the stacked engine on the GPU: two ranks (two processes sharing the one
+GPU of the test box, gloo transport) run the same replica on different shards; after the exchange every rank's per-task
+gradient matrix equals the arithmetic mean of the two single-rank matrices on every (task, tensor) pair that carries a
+gradient, and after the identical PCGrad / clip / AdamW the replicas are bit-identical."""
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(seed, sync):
+    from gnn_pretraining_amd.engine import StepEngine
+    from gnn_pretraining_amd.models.pretrain_model import PretrainableGNN
+    from gnn_pretraining_amd.pretrain import pretrain as PT
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    model = PretrainableGNN(device=dev, domain_names=PT.PRETRAIN_DOMAINS["s4"], task_names=PT.ACTIVE_TASKS["s4"])
+    model.train()
+    eng = StepEngine(model, PT.ACTIVE_TASKS["s4"], PT.PRETRAIN_DOMAINS["s4"], dev, seed=seed, shuffle_rng=random.Random(5),
+                     grad_sync=sync, rng_mode="vectorized")
+    return model, eng
+
+
+def _inputs(rank, eng):
+    from gnn_pretraining_amd import synthetic as S
+    from gnn_pretraining_amd.engine import StepInputs
+    from gnn_pretraining_amd.pretrain import pretrain as PT
+    gen = torch.Generator().manual_seed(1000 + rank)                       # a different shard per rank
+    return StepInputs(S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"]), eng.device, eng.dpad), gen
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from gnn_pretraining_amd import dist as D
+    D.init_from_env("gloo")
+    model, eng = _build(3, D.FlatGradSync())
+    inp, gen = _inputs(rank, eng)
+    eng.step(inp, gen)
+    torch.cuda.synchronize()
+    out[rank] = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu()}
+    dist.destroy_process_group()
+
+
+def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    # single-rank per-task gradients of the two shards, same replica, no exchange, no update
+    singles = []
+    for r in range(world):
+        model, eng = _build(3, None)
+        inp, gen = _inputs(r, eng)
+        eng.step(inp, gen, apply_update=False)
+        torch.cuda.synchronize()
+        singles.append(eng.task_grads.cpu())
+        has, off, numel, names, P = eng.has_static, eng.off, eng.numel, eng.names, eng.P
+    mean = (singles[0] + singles[1]) / 2
+    got = out[0]["tg"]
+    checked = 0
+    for k, n in enumerate(names):
+        for t in range(got.size(0)):
+            if has[k][t]:
+                a, b = got[t, off[n]:off[n] + numel[n]], mean[t, off[n]:off[n] + numel[n]]
+                scale = max(float(b.abs().max()), 1e-6)
+                assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-9, f"{n} task {t}"
+                checked += 1
+    assert checked > 100
+    assert torch.equal(out[0]["flat"], out[1]["flat"])                      # identical update on both ranks
+    assert torch.equal(out[0]["tg"], out[1]["tg"])
