@@ -109,6 +109,16 @@ class ViewArrays:
         self.rows, self.edges, self.ptr, self.rowmask, self.common = rows, edges, ptr, rowmask, common
 
 
+def _empty_views():
+    z, e = np.zeros(0, dtype=np.int64), np.zeros((2, 0), dtype=np.int64)
+    return (ViewArrays(z, e, np.zeros(1, dtype=np.int64), None, z), ViewArrays(z.copy(), e.copy(), np.zeros(1, dtype=np.int64), None, z.copy()))
+
+
+# what draw() records for a domain that has no graph in this step
+_EMPTY_ART = {"node_feat_mask": lambda: np.zeros(0, dtype=np.int64), "link_pred": lambda: np.zeros((2, 0), dtype=np.int64),
+              "node_contrast": _empty_views, "graph_contrast": lambda: None, "domain_adv": lambda: None}
+
+
 class StepEngine:
     def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
@@ -310,11 +320,12 @@ class StepEngine:
         host = {d: inp.host[d] for d in self.domains}
         for t in self.tasks:
             if t == "node_feat_mask":
-                art[t] = {d: draw_mask_indices(b.ptr_host, gen).numpy() for d, b in host.items()}
+                art[t] = {d: (draw_mask_indices(b.ptr_host, gen).numpy() if b.num_graphs else _EMPTY_ART[t]()) for d, b in host.items()}
             elif t == "link_pred":
-                art[t] = {d: sample_negative_edges(b, gen).numpy() for d, b in host.items()}
+                art[t] = {d: (sample_negative_edges(b, gen).numpy() if b.num_graphs else _EMPTY_ART[t]()) for d, b in host.items()}
             elif t in ("node_contrast", "graph_contrast"):
-                art[t] = {d: (self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
+                art[t] = {d: (_EMPTY_ART[t]() if b.num_graphs == 0 else
+                              self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
                           for d, b in host.items()}
         return art
 
@@ -430,6 +441,9 @@ class StepEngine:
                 continue
             out = art[t] = {}
             for d in self.domains:
+                if inp.host[d].num_graphs == 0:          # a domain absent from this step (single-domain validation passes)
+                    out[d] = _EMPTY_ART[t]()
+                    continue
                 st = self._static(inp, d)
                 n, ng, ptr = st["n"], st["node_graph"], st["ptr"]
                 if t == "node_feat_mask":

@@ -86,6 +86,13 @@ class Batch:
               if graphs[0].graph_properties is not None else None)
         return Batch(x, ei, batch, ptr, ptr_h, eptr_h, y, gp)
 
+    @staticmethod
+    def empty(num_node_features: int, with_properties: bool = True) -> "Batch":
+        """A batch of zero graphs (a domain absent from a step, e.g. single-domain validation passes on the stacked engine)."""
+        z = torch.zeros(0, dtype=torch.long)
+        return Batch(torch.zeros(0, num_node_features), torch.zeros(2, 0, dtype=torch.long), z, torch.zeros(1, dtype=torch.long), [0], [0],
+                     z.clone(), torch.zeros(0) if with_properties else None)
+
     def to_data_list(self) -> List[Data]:
         B = self.num_graphs
         gp = None if self.graph_properties is None else self.graph_properties.view(B, -1)

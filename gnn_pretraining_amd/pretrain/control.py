@@ -83,6 +83,12 @@ class AdaptiveLossBalancer:
     def get_current_weights(self) -> Dict[str, float]:
         return self.current_weights
 
+    def tick(self) -> None:
+        """What a training step's balance_losses call leaves behind when its value is not needed (the stacked engine runs
+        PCGrad on the per-task losses and never forms the total): the call counter that ends the warm-up.  The weights
+        themselves are a function of the current losses only."""
+        self.step_count += 1
+
 
 class GradientSurgery:
     """PCGrad with the reference's exact semantics, including its gradient-setting quirk

@@ -1,0 +1,59 @@
+"""GPU time of the s4 step with the host taken out: one prepared step is re-enqueued back to back (no draw / plan / upload)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+from gnn_pretraining_amd.engine import StepEngine
+from gnn_pretraining_amd.models.pretrain_model import PretrainableGNN
+from gnn_pretraining_amd.pretrain import pretrain as PT
+
+dev = torch.device("cuda:0")
+torch.set_num_threads(1)
+model = PretrainableGNN(device=dev, domain_names=PT.PRETRAIN_DOMAINS["s4"], task_names=PT.ACTIVE_TASKS["s4"])
+model.train()
+eng = StepEngine(model, PT.ACTIVE_TASKS["s4"], PT.PRETRAIN_DOMAINS["s4"], dev, seed=0, rng_mode="vectorized")
+pool = B.make_pool(0, dev, eng.dpad)
+gen = torch.Generator().manual_seed(0)
+for k in range(20):
+    eng.step(pool[k % len(pool)], gen)
+p, inp = eng.last_plan, pool[19 % len(pool)]
+torch.cuda.synchronize()
+for reps in (100, 300):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    a.record()
+    for _ in range(reps):
+        eng._forward_backward_native(p, inp)
+        eng._optimizer(p, None, True)
+    b.record()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"{reps} re-enqueued steps: GPU {a.elapsed_time(b) / reps:.3f} ms/step, host enqueue {(t1 - t0) / reps * 1e3:.3f} ms/step")
+
+# where the host time goes
+import ctypes as C
+T = dict(fill=0.0, native=0.0, opt=0.0)
+reps = 200
+main = torch.cuda.current_stream(dev)
+for _ in range(reps):
+    t0 = time.perf_counter()
+    d = eng._fill_desc(p, inp)
+    t1 = time.perf_counter()
+    eng._chk(eng.lib.gmp_pretrain_step_fwd_bwd(C.byref(d), main.cuda_stream, eng._stream_arr, eng.aux_stream.cuda_stream), "x")
+    t2 = time.perf_counter()
+    eng._optimizer(p, None, True)
+    t3 = time.perf_counter()
+    T["fill"] += t1 - t0; T["native"] += t2 - t1; T["opt"] += t3 - t2
+torch.cuda.synchronize()
+print({k: round(v / reps * 1e3, 3) for k, v in T.items()}, "ms/step host")
+
+ts = []
+for _ in range(30):
+    torch.cuda.synchronize()
+    d = eng._fill_desc(p, inp)
+    t1 = time.perf_counter()
+    eng._chk(eng.lib.gmp_pretrain_step_fwd_bwd(C.byref(d), main.cuda_stream, eng._stream_arr, eng.aux_stream.cuda_stream), "x")
+    t2 = time.perf_counter()
+    ts.append((t2 - t1) * 1e3)
+ts.sort()
+print("native enqueue with idle GPU: median %.3f ms, min %.3f ms" % (ts[len(ts) // 2], ts[0]))

@@ -211,3 +211,32 @@ def test_engine_s5_step_with_domain_adversarial_term():
     num = sum(((after_h[k].cpu() - after_o[k]).double() ** 2).sum().item() for k in moved_o)
     den = sum(((after_o[k] - before[k]).double() ** 2).sum().item() for k in moved_o)
     assert (num / den) ** 0.5 <= 2e-2, f"relative update error {(num / den) ** 0.5:.3e}"
+
+
+@pytest.mark.parametrize("present,rng_mode", [(["ENZYMES"], "reference"), (["PROTEINS"], "vectorized"), (["MUTAG", "NCI1"], "reference")])
+def test_engine_eval_mode_with_absent_domains_matches_oracle(present, rng_mode):
+    """Validation passes (pretrain.py:193-281) give the engine ONE domain's batch at a time, in eval mode: BatchNorm
+    uses the running statistics, dropout is off, the other domains are empty batches.  Per-task losses equal the
+    oracle's task.compute_loss({domain: batch}) with the same draws, and nothing of the model state moves."""
+    from gnn_pretraining_amd.constants import DOMAIN_DIMENSIONS
+    from gnn_pretraining_amd.graph import Batch
+    om, hm, eng, _, _, gen, tasks, domains = build("s4", 61, rng_mode)
+    eng = StepEngine(hm, tasks, domains, DEV, seed=61, rng_mode=rng_mode, max_rows=65536, max_edges=524288)
+    om.eval(); hm.eval()
+    real = S.pretrain_step_batches(gen, present, graphs_per_domain=32)          # validation batches hold 32 graphs
+    host = {d: (real[d] if d in real else Batch.empty(DOMAIN_DIMENSIONS[d])) for d in domains}
+    inp = StepInputs(host, DEV, eng.dpad)
+    before = {k: v.clone() for k, v in hm.state_dict().items()}
+    art = eng.draw(inp, gen)
+    eng.temperature = 0.41
+    eng.step(inp, gen, art=art, apply_update=False)
+    got = eng.losses()
+    otasks = OTk.instantiate_tasks(om, tasks, lambda: 0.0, lambda: 0.41)
+    o_batches = {d: to_oracle(real[d]) for d in present}
+    o_art = {t: {d: a[d] for d in present} for t, a in oracle_artefacts(art, host).items()}
+    with torch.no_grad():
+        for name in tasks:
+            lo, _ = otasks[name].loss(o_batches, o_art.get(name))
+            assert abs(got[name] - lo.item()) <= 1e-4 * abs(lo.item()), (name, got[name], lo.item())
+    after = hm.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)                # eval: no running-statistics update, no step
