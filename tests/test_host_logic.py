@@ -1,5 +1,6 @@
 """CPU tests of the host-side logic of the product path (no kernels): augmentation / masking index
 parity with the oracle for an equal generator state (bit-exact), Batch collation."""
+import pytest
 import torch
 
 from gnn_pretraining_amd import synthetic as S
@@ -147,3 +148,28 @@ def test_plan_layout_is_task_major_and_consistent():
         assert np.array_equal(seg_of_row[ei[0]], seg_of_row[ei[1]])           # block diagonal: no edge crosses a segment
         assert p.a32["tiles"].shape == (p.num_tiles, 2)
         assert (p.a64["nfm_idx"] < p.task_row[1]).all() and (p.a64["nc_idx"] >= p.task_row[2]).all()
+
+
+@pytest.mark.parametrize("mode", ["reference", "vectorized"])
+@pytest.mark.parametrize("scheme", ["s4", "s5"])
+def test_plan_accepts_steps_with_absent_domains(mode, scheme):
+    """Validation passes hand the engine one domain at a time: the others are zero-graph batches.  Their segments exist
+    (the layout stays task-major x domain) but are empty, and every row / edge of the plan belongs to a present domain."""
+    from gnn_pretraining_amd.constants import DOMAIN_DIMENSIONS
+    from gnn_pretraining_amd.graph import Batch
+    e = _planner(mode, scheme)
+    for present in (["ENZYMES"], ["MUTAG", "NCI1"], []):
+        gen = torch.Generator().manual_seed(3)
+        real = S.pretrain_step_batches(gen, present, graphs_per_domain=5) if present else {}
+        host = {d: (real[d] if d in real else Batch.empty(DOMAIN_DIMENSIONS[d])) for d in e.domains}
+        inp = _Inp(host)
+        p = e.plan(inp, e.draw(inp, gen))
+        seg_ptr, seg_dom = p.a32["seg_ptr"], p.a32["seg_dom"]
+        lens = np.diff(seg_ptr)
+        absent = [i for i, d in enumerate(e.domains) if d not in present]
+        assert p.S == len(seg_dom) and int(seg_ptr[-1]) == p.N
+        assert all(lens[seg_dom == i].sum() == 0 for i in absent)
+        if not present:
+            assert p.N == 0 and p.E == 0
+        else:
+            assert p.N > 0 and lens[np.isin(seg_dom, [e.domains.index(d) for d in present])].sum() == p.N
