@@ -220,6 +220,7 @@ def main() -> None:
         }
         print(json.dumps(line))
     if world > 1:
+        torch.distributed.barrier()                 # rank 0 may still be in its roofline leg: leave together
         torch.distributed.destroy_process_group()
 
 
