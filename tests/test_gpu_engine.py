@@ -21,7 +21,7 @@ from test_gpu_modules import perturb_bn                                         
 DEV = torch.device("cuda:0")
 
 
-def build(scheme, seed, rng_mode="reference"):
+def build(scheme, seed, rng_mode="reference", make_host=None, **engine_kw):
     tasks, domains = PT.ACTIVE_TASKS[scheme], PT.PRETRAIN_DOMAINS[scheme]
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
@@ -35,9 +35,9 @@ def build(scheme, seed, rng_mode="reference"):
     hm.to(DEV)
     set_dropout(om, 0.0)
     om.train(); hm.train()
-    eng = StepEngine(hm, tasks, domains, DEV, seed=seed, rng_mode=rng_mode)
+    eng = StepEngine(hm, tasks, domains, DEV, seed=seed, rng_mode=rng_mode, **engine_kw)
     eng.dropout_p = eng.da_dropout = 0.0
-    host = S.pretrain_step_batches(gen, domains)
+    host = make_host(gen, domains) if make_host is not None else S.pretrain_step_batches(gen, domains)
     inp = StepInputs(host, DEV, eng.dpad)
     return om, hm, eng, host, inp, gen, tasks, domains
 
@@ -240,3 +240,56 @@ def test_engine_eval_mode_with_absent_domains_matches_oracle(present, rng_mode):
             assert abs(got[name] - lo.item()) <= 1e-4 * abs(lo.item()), (name, got[name], lo.item())
     after = hm.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before)                # eval: no running-statistics update, no step
+
+
+def _ragged_host(gen, domains):
+    """Edge cases in one step: a domain with a single graph (graph-level contrast skips it), one with two graphs, graphs
+    of 3 nodes (no node is dropped / masked below 3... the >= 3 rules), a graph without edges, a 126-node graph (the
+    synthetic maximum), and a 40-graph domain whose segments exceed the 512-row short BatchNorm regime."""
+    from gnn_pretraining_amd.constants import DOMAIN_DIMENSIONS
+    from gnn_pretraining_amd.graph import Batch, Data
+    def g(n, dim, edges=None, m=None):
+        if edges is None:
+            pairs = n * (n - 1) // 2
+            m = min(m if m is not None else 2 * n, pairs)
+            pick = torch.randperm(pairs, generator=gen)[:m]
+            iu = torch.triu_indices(n, n, offset=1)
+            a, b = iu[0][pick], iu[1][pick]
+            edges = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+        return Data(torch.randn(n, dim, generator=gen).clamp_(-3, 3), edges, torch.zeros(1, dtype=torch.long), torch.randn(12, generator=gen))
+    out = {}
+    d0, d1, d2, d3 = domains
+    out[d0] = Batch.from_data_list([g(126, DOMAIN_DIMENSIONS[d0])])
+    out[d1] = Batch.from_data_list([g(3, DOMAIN_DIMENSIONS[d1], m=2), g(5, DOMAIN_DIMENSIONS[d1], edges=torch.zeros(2, 0, dtype=torch.long))])
+    out[d2] = Batch.from_data_list([g(3, DOMAIN_DIMENSIONS[d2], m=3), g(4, DOMAIN_DIMENSIONS[d2], m=3), g(60, DOMAIN_DIMENSIONS[d2]),
+                                    g(9, DOMAIN_DIMENSIONS[d2], m=8)])
+    out[d3] = Batch.from_data_list([g(int(torch.randint(20, 45, (1,), generator=gen)), DOMAIN_DIMENSIONS[d3]) for _ in range(40)])
+    return out
+
+
+@pytest.mark.parametrize("rng_mode", ["reference", "vectorized"])
+def test_engine_ragged_step_losses_and_task_gradients(rng_mode):
+    om, hm, eng, host, inp, gen, tasks, domains = build("s4", 71, rng_mode, make_host=_ragged_host, max_rows=32768, max_edges=262144)
+    assert max(b.num_nodes for b in host.values()) > 512                     # long BatchNorm regime in play
+    art = eng.draw(inp, gen)
+    assert art["graph_contrast"][domains[0]] is None                         # one graph: nothing to contrast
+    eng.temperature = 0.3
+    eng.step(inp, gen, art=art, order=list(tasks), apply_update=False)
+    got = eng.losses()
+    o_batches = {d: to_oracle(b) for d, b in host.items()}
+    otasks = OTk.instantiate_tasks(om, tasks, lambda: 0.0, lambda: 0.3)
+    o_art = oracle_artefacts(art, host)
+    names = dict(om.named_parameters())
+    for name in tasks:
+        om.zero_grad(set_to_none=True)
+        lo, _ = otasks[name].loss(o_batches, o_art.get(name))
+        assert abs(got[name] - lo.item()) <= 1e-4 * abs(lo.item()), (name, got[name], lo.item())
+        lo.backward()
+        gmax = max(p.grad.abs().max().item() for p in names.values() if p.grad is not None)
+        for n, p in names.items():
+            if p.grad is not None:
+                assert_grad_close(eng.task_gradient(name, n), p.grad, gmax, f"{name}: grad {n}")
+    osd, hsd = om.state_dict(), hm.state_dict()
+    for k, v in osd.items():
+        if "running_" in k:
+            assert_close(hsd[k], v, 1e-4, f"buffer {k}")
