@@ -867,109 +867,108 @@ class StepEngine:
         """Head forward, loss, and head backward of ONE task (writes its rows of gH and its slots of task_grads)."""
         lib, st, N, D, P, TG = self.lib, self._st(), p.N, self.domains, self._P, self._TG
         hd, tg = self.hd, self.task_grads.data_ptr()
-        if True:
-            gs = sc + 4 * ti                                        # device scalar 1/size_t: d total_t / d loss_sum
-            ls = self.loss_sums.data_ptr() + 4 * ti
-            if t == "node_feat_mask":
-                rows, M = p.nfm_rows, p.nfm_rows[-1]
-                if M == 0:
-                    return
-                self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nfm_idx"], None, hd["nfm_in"].data_ptr(), M, N, H, st), "nfm gather")
-                d1 = self._mlp2_grouped(ti, t, hd["nfm_in"], rows, H, H, H, (hd["nfm_y1"], hd["nfm_d1"], hd["nfm_y2"]), 100 + ti)
-                self._chk(lib.gmp_mse_sum_fwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), M * H, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "mse")
-                self._chk(lib.gmp_mse_sum_bwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), gs, hd["nfm_g"].data_ptr(), M * H, st), "mse bwd")
-                self._mlp2_grouped_bwd(ti, t, hd["nfm_in"], rows, H, H, H, hd["nfm_y1"], d1, hd["nfm_g"], hd["nfm_g1"], hd["nfm_y2"], 100 + ti)
-                self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nfm_idx"], hd["nfm_y2"].data_ptr(), M, N, H, 0, st), "nfm scatter")
-            elif t == "link_pred":
-                K = p.lp_K
-                w0, b0 = P("heads.link_pred.predictor.mlp.0.weight"), P("heads.link_pred.predictor.mlp.0.bias")
-                w3, b3 = P("heads.link_pred.predictor.mlp.3.weight"), P("heads.link_pred.predictor.mlp.3.bias")
-                self._chk(lib.gmp_lp_edge_features_fwd(hL.data_ptr(), p.d64["lp_edges"], hd["lp_feat"].data_ptr(), N, K, H, st), "lp feat")
-                self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
-                d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
-                self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
-                self._chk(lib.gmp_sigmoid_fwd(self.lp_y2.data_ptr(), self.lp_p.data_ptr(), K, st), "sigmoid")
-                self._chk(lib.gmp_bce_sum_fwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), K, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "bce")
-                self._chk(lib.gmp_bce_sum_bwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), gs, self.lp_gp.data_ptr(), K, st), "bce bwd")
-                self._chk(lib.gmp_sigmoid_bwd(self.lp_gp.data_ptr(), self.lp_p.data_ptr(), self.lp_gy2.data_ptr(), K, st), "sigmoid bwd")
-                one = [0, K]
-                self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],
-                             tg, [TG(ti, "heads.link_pred.predictor.mlp.3.bias")], 1, H, 0, 1, H, H)
-                self._gemm(NN, self.lp_gy2.data_ptr(), w3, None, hd["lp_gy1"].data_ptr(), K, H, 1, 1, H, H)
-                self._relu_drop_bwd(hd["lp_gy1"], hd["lp_y1"], hd["lp_gy1"], K * H, 100 + ti)
-                wsb = lib.gmp_gemm_f32_workspace_bytes(TN, H, 3 * H, K)
-                if wsb > self.hd["lp_gfeat"].numel() * 4:
-                    wsb = 0
-                self._chk(lib.gmp_gemm_f32(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.weight"),
-                                           H, 3 * H, K, H, 3 * H, 3 * H, 1.0, 0, 0, hd["lp_gfeat"].data_ptr() if wsb else None, wsb, st), "lp dW0")
-                self._chk(lib.gmp_colsum(hd["lp_gy1"].data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.bias"), K, H, H, 0,
-                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "lp db0")
-                self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
-                self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
-                                                       hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")
-                # reduce the per-edge gradients onto nodes -- only over this task's own rows (other tasks' heads are
-                # writing their rows of gH concurrently on their own streams)
-                c = self.lp_csr
-                r0, r1 = p.task_row[ti], p.task_row[ti + 1]
-                g_rows = gH.data_ptr() + 4 * H * r0
-                self._chk(lib.gmp_segment_sum(hd["lp_ghs"].data_ptr(), c[3].data_ptr() + 4 * r0, c[5].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by src")
-                self._chk(lib.gmp_segment_sum(hd["lp_ghd"].data_ptr(), c[0].data_ptr() + 4 * r0, c[2].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by dst")
-            elif t == "node_contrast":
-                rows, M = p.nc_rows, p.nc_rows[-1]
-                if M == 0:
-                    return
-                self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nc_idx"], None, hd["nc_in"].data_ptr(), M, N, H, st), "nc gather")
-                d1 = self._mlp2_grouped(ti, t, hd["nc_in"], rows, H, H, 128, (hd["nc_y1"], hd["nc_d1"], hd["nc_z"]), 100 + ti)
-                self._nt_xent_domains(p.nc_n, rows, hd["nc_z"], hd["nc_gz"], gs, ls, T_, 0)
-                self._mlp2_grouped_bwd(ti, t, hd["nc_in"], rows, H, H, 128, hd["nc_y1"], d1, hd["nc_gz"], hd["nc_g1"], hd["nc_gin"], 100 + ti)
-                self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nc_idx"], hd["nc_gin"].data_ptr(), M, N, H, 0, st), "nc scatter")
-            elif t == "graph_contrast":
-                rows, B = p.gc_rows, p.gc_B
-                if B == 0:
-                    return
-                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gc_ptr"], None, hd["gc_mean"].data_ptr(), B, H, 1, 0, st), "gc mean")
-                self._chk(lib.gmp_segment_max_fwd(hL.data_ptr(), p.d32["gc_ptr"], hd["gc_max"].data_ptr(), B, H, st), "gc max")
-                torch.cat([hd["gc_mean"][:B], hd["gc_max"][:B]], dim=1, out=hd["gc_in"][:B])
-                d1 = self._mlp2_grouped(ti, t, hd["gc_in"], rows, 2 * H, H, 128, (hd["gc_y1"], hd["gc_d1"], hd["gc_z"]), 100 + ti)
-                self._nt_xent_domains(p.gc_n, rows, hd["gc_z"], hd["gc_gz"], gs, ls, T_, self.D)
-                self._mlp2_grouped_bwd(ti, t, hd["gc_in"], rows, 2 * H, H, 128, hd["gc_y1"], d1, hd["gc_gz"], hd["gc_g1"], hd["gc_gin"], 100 + ti)
-                hd["gc_gmean"][:B].copy_(hd["gc_gin"][:B, :H])
-                hd["gc_gmax"][:B].copy_(hd["gc_gin"][:B, H:])
-                g_rows = gH.data_ptr() + 4 * H * p.gc_r0
-                self._chk(lib.gmp_row_gather(hd["gc_gmean"].data_ptr(), p.d64["gc_gid"], p.d32["gc_ptr"], g_rows, p.gc_M, B, H, st), "gc mean bwd")
-                self._chk(lib.gmp_segment_max_bwd(hd["gc_gmax"].data_ptr(), hL.data_ptr(), hd["gc_max"].data_ptr(), p.d32["gc_ptr"], gH.data_ptr(),
-                                                  B, H, 1, st), "gc max bwd")
-            elif t == "graph_prop":
-                rows, B = p.gp_rows, p.gp_B
-                G = GRAPH_PROPERTY_DIM
-                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gp_ptr"], None, hd["gp_in"].data_ptr(), B, H, 1, 0, st), "gp mean")
-                d1 = self._mlp2_grouped(ti, t, hd["gp_in"], rows, H, 2 * H, G, (hd["gp_y1"], hd["gp_d1"], self.gp_y2), 100 + ti)
-                self._chk(lib.gmp_mse_sum_fwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), B * G, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "gp mse")
-                self._chk(lib.gmp_mse_sum_bwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), gs, self.gp_g2.data_ptr(), B * G, st), "gp mse bwd")
-                self._mlp2_grouped_bwd(ti, t, hd["gp_in"], rows, H, 2 * H, G, hd["gp_y1"], d1, self.gp_g2, hd["gp_g1"], hd["gp_gin"], 100 + ti)
-                g_rows = gH.data_ptr() + 4 * H * p.gp_r0
-                self._chk(lib.gmp_row_gather(hd["gp_gin"].data_ptr(), p.d64["gp_gid"], p.d32["gp_ptr"], g_rows, p.gp_M, B, H, st), "gp mean bwd")
-            elif t == "domain_adv":
-                # mean read-out -> gradient reversal -> Linear 256->128, ReLU, Dropout(.5), Linear 128->D -> CE(sum)  (heads.py:70-82)
-                B, Cc, lam = p.da_B, len(D), float(self.grl_lambda)
-                pre = "heads.domain_adv.classifier.mlp."
-                w0, b0, w3, b3 = P(pre + "0.weight"), P(pre + "0.bias"), P(pre + "3.weight"), P(pre + "3.bias")
-                self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["da_ptr"], None, hd["da_in"].data_ptr(), B, H, 1, 0, st), "da mean")
-                self._gemm(NT, hd["da_in"].data_ptr(), w0, b0, hd["da_y1"].data_ptr(), B, DA_HIDDEN, H, H, H, DA_HIDDEN, relu=True)
-                d1 = self._drop(hd["da_y1"], hd["da_d1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
-                self._gemm(NT, d1.data_ptr(), w3, b3, hd["da_logits"].data_ptr(), B, Cc, DA_HIDDEN, DA_HIDDEN, DA_HIDDEN, Cc)
-                self._chk(lib.gmp_cross_entropy_sum_fwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "da ce")
-                self._chk(lib.gmp_cross_entropy_sum_bwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, gs, hd["da_glogits"].data_ptr(), st), "da ce bwd")
-                one = [0, B]
-                self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_glogits"].data_ptr(), d1.data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "3.weight")]),
-                                                   tg, _i64([TG(ti, pre + "3.bias")]), Cc, DA_HIDDEN, 0, Cc, DA_HIDDEN, DA_HIDDEN, 1.0, 0, 0, None, 0, st), "da dW3")
-                self._gemm(NN, hd["da_glogits"].data_ptr(), w3, None, hd["da_g1"].data_ptr(), B, DA_HIDDEN, Cc, Cc, DA_HIDDEN, DA_HIDDEN)
-                self._relu_drop_bwd(hd["da_g1"], hd["da_y1"], hd["da_g1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
-                self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_g1"].data_ptr(), hd["da_in"].data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "0.weight")]),
-                                                   tg, _i64([TG(ti, pre + "0.bias")]), DA_HIDDEN, H, 0, DA_HIDDEN, H, H, 1.0, 0, 0, None, 0, st), "da dW0")
-                self._chk(lib.gmp_gemm_f32(NN, hd["da_g1"].data_ptr(), w0, None, hd["da_gin"].data_ptr(), B, H, DA_HIDDEN, DA_HIDDEN, H, H, -lam, 0, 0, None, 0, st), "da grl")
-                g_rows = gH.data_ptr() + 4 * H * p.da_r0
-                self._chk(lib.gmp_row_gather(hd["da_gin"].data_ptr(), p.d64["da_gid"], p.d32["da_ptr"], g_rows, p.da_M, B, H, st), "da mean bwd")
+        gs = sc + 4 * ti                                        # device scalar 1/size_t: d total_t / d loss_sum
+        ls = self.loss_sums.data_ptr() + 4 * ti
+        if t == "node_feat_mask":
+            rows, M = p.nfm_rows, p.nfm_rows[-1]
+            if M == 0:
+                return
+            self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nfm_idx"], None, hd["nfm_in"].data_ptr(), M, N, H, st), "nfm gather")
+            d1 = self._mlp2_grouped(ti, t, hd["nfm_in"], rows, H, H, H, (hd["nfm_y1"], hd["nfm_d1"], hd["nfm_y2"]), 100 + ti)
+            self._chk(lib.gmp_mse_sum_fwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), M * H, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "mse")
+            self._chk(lib.gmp_mse_sum_bwd(hd["nfm_y2"].data_ptr(), hd["nfm_tgt"].data_ptr(), gs, hd["nfm_g"].data_ptr(), M * H, st), "mse bwd")
+            self._mlp2_grouped_bwd(ti, t, hd["nfm_in"], rows, H, H, H, hd["nfm_y1"], d1, hd["nfm_g"], hd["nfm_g1"], hd["nfm_y2"], 100 + ti)
+            self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nfm_idx"], hd["nfm_y2"].data_ptr(), M, N, H, 0, st), "nfm scatter")
+        elif t == "link_pred":
+            K = p.lp_K
+            w0, b0 = P("heads.link_pred.predictor.mlp.0.weight"), P("heads.link_pred.predictor.mlp.0.bias")
+            w3, b3 = P("heads.link_pred.predictor.mlp.3.weight"), P("heads.link_pred.predictor.mlp.3.bias")
+            self._chk(lib.gmp_lp_edge_features_fwd(hL.data_ptr(), p.d64["lp_edges"], hd["lp_feat"].data_ptr(), N, K, H, st), "lp feat")
+            self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
+            d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
+            self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
+            self._chk(lib.gmp_sigmoid_fwd(self.lp_y2.data_ptr(), self.lp_p.data_ptr(), K, st), "sigmoid")
+            self._chk(lib.gmp_bce_sum_fwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), K, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "bce")
+            self._chk(lib.gmp_bce_sum_bwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), gs, self.lp_gp.data_ptr(), K, st), "bce bwd")
+            self._chk(lib.gmp_sigmoid_bwd(self.lp_gp.data_ptr(), self.lp_p.data_ptr(), self.lp_gy2.data_ptr(), K, st), "sigmoid bwd")
+            one = [0, K]
+            self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],
+                         tg, [TG(ti, "heads.link_pred.predictor.mlp.3.bias")], 1, H, 0, 1, H, H)
+            self._gemm(NN, self.lp_gy2.data_ptr(), w3, None, hd["lp_gy1"].data_ptr(), K, H, 1, 1, H, H)
+            self._relu_drop_bwd(hd["lp_gy1"], hd["lp_y1"], hd["lp_gy1"], K * H, 100 + ti)
+            wsb = lib.gmp_gemm_f32_workspace_bytes(TN, H, 3 * H, K)
+            if wsb > self.hd["lp_gfeat"].numel() * 4:
+                wsb = 0
+            self._chk(lib.gmp_gemm_f32(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.weight"),
+                                       H, 3 * H, K, H, 3 * H, 3 * H, 1.0, 0, 0, hd["lp_gfeat"].data_ptr() if wsb else None, wsb, st), "lp dW0")
+            self._chk(lib.gmp_colsum(hd["lp_gy1"].data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.bias"), K, H, H, 0,
+                                     self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "lp db0")
+            self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
+            self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
+                                                   hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")
+            # reduce the per-edge gradients onto nodes -- only over this task's own rows (other tasks' heads are
+            # writing their rows of gH concurrently on their own streams)
+            c = self.lp_csr
+            r0, r1 = p.task_row[ti], p.task_row[ti + 1]
+            g_rows = gH.data_ptr() + 4 * H * r0
+            self._chk(lib.gmp_segment_sum(hd["lp_ghs"].data_ptr(), c[3].data_ptr() + 4 * r0, c[5].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by src")
+            self._chk(lib.gmp_segment_sum(hd["lp_ghd"].data_ptr(), c[0].data_ptr() + 4 * r0, c[2].data_ptr(), g_rows, r1 - r0, H, 0, 1, st), "lp g by dst")
+        elif t == "node_contrast":
+            rows, M = p.nc_rows, p.nc_rows[-1]
+            if M == 0:
+                return
+            self._chk(lib.gmp_row_gather(hL.data_ptr(), p.d64["nc_idx"], None, hd["nc_in"].data_ptr(), M, N, H, st), "nc gather")
+            d1 = self._mlp2_grouped(ti, t, hd["nc_in"], rows, H, H, 128, (hd["nc_y1"], hd["nc_d1"], hd["nc_z"]), 100 + ti)
+            self._nt_xent_domains(p.nc_n, rows, hd["nc_z"], hd["nc_gz"], gs, ls, T_, 0)
+            self._mlp2_grouped_bwd(ti, t, hd["nc_in"], rows, H, H, 128, hd["nc_y1"], d1, hd["nc_gz"], hd["nc_g1"], hd["nc_gin"], 100 + ti)
+            self._chk(lib.gmp_row_fill(gH.data_ptr(), p.d64["nc_idx"], hd["nc_gin"].data_ptr(), M, N, H, 0, st), "nc scatter")
+        elif t == "graph_contrast":
+            rows, B = p.gc_rows, p.gc_B
+            if B == 0:
+                return
+            self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gc_ptr"], None, hd["gc_mean"].data_ptr(), B, H, 1, 0, st), "gc mean")
+            self._chk(lib.gmp_segment_max_fwd(hL.data_ptr(), p.d32["gc_ptr"], hd["gc_max"].data_ptr(), B, H, st), "gc max")
+            torch.cat([hd["gc_mean"][:B], hd["gc_max"][:B]], dim=1, out=hd["gc_in"][:B])
+            d1 = self._mlp2_grouped(ti, t, hd["gc_in"], rows, 2 * H, H, 128, (hd["gc_y1"], hd["gc_d1"], hd["gc_z"]), 100 + ti)
+            self._nt_xent_domains(p.gc_n, rows, hd["gc_z"], hd["gc_gz"], gs, ls, T_, self.D)
+            self._mlp2_grouped_bwd(ti, t, hd["gc_in"], rows, 2 * H, H, 128, hd["gc_y1"], d1, hd["gc_gz"], hd["gc_g1"], hd["gc_gin"], 100 + ti)
+            hd["gc_gmean"][:B].copy_(hd["gc_gin"][:B, :H])
+            hd["gc_gmax"][:B].copy_(hd["gc_gin"][:B, H:])
+            g_rows = gH.data_ptr() + 4 * H * p.gc_r0
+            self._chk(lib.gmp_row_gather(hd["gc_gmean"].data_ptr(), p.d64["gc_gid"], p.d32["gc_ptr"], g_rows, p.gc_M, B, H, st), "gc mean bwd")
+            self._chk(lib.gmp_segment_max_bwd(hd["gc_gmax"].data_ptr(), hL.data_ptr(), hd["gc_max"].data_ptr(), p.d32["gc_ptr"], gH.data_ptr(),
+                                              B, H, 1, st), "gc max bwd")
+        elif t == "graph_prop":
+            rows, B = p.gp_rows, p.gp_B
+            G = GRAPH_PROPERTY_DIM
+            self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["gp_ptr"], None, hd["gp_in"].data_ptr(), B, H, 1, 0, st), "gp mean")
+            d1 = self._mlp2_grouped(ti, t, hd["gp_in"], rows, H, 2 * H, G, (hd["gp_y1"], hd["gp_d1"], self.gp_y2), 100 + ti)
+            self._chk(lib.gmp_mse_sum_fwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), B * G, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "gp mse")
+            self._chk(lib.gmp_mse_sum_bwd(self.gp_y2.data_ptr(), inp.graph_props.data_ptr(), gs, self.gp_g2.data_ptr(), B * G, st), "gp mse bwd")
+            self._mlp2_grouped_bwd(ti, t, hd["gp_in"], rows, H, 2 * H, G, hd["gp_y1"], d1, self.gp_g2, hd["gp_g1"], hd["gp_gin"], 100 + ti)
+            g_rows = gH.data_ptr() + 4 * H * p.gp_r0
+            self._chk(lib.gmp_row_gather(hd["gp_gin"].data_ptr(), p.d64["gp_gid"], p.d32["gp_ptr"], g_rows, p.gp_M, B, H, st), "gp mean bwd")
+        elif t == "domain_adv":
+            # mean read-out -> gradient reversal -> Linear 256->128, ReLU, Dropout(.5), Linear 128->D -> CE(sum)  (heads.py:70-82)
+            B, Cc, lam = p.da_B, len(D), float(self.grl_lambda)
+            pre = "heads.domain_adv.classifier.mlp."
+            w0, b0, w3, b3 = P(pre + "0.weight"), P(pre + "0.bias"), P(pre + "3.weight"), P(pre + "3.bias")
+            self._chk(lib.gmp_segment_sum(hL.data_ptr(), p.d32["da_ptr"], None, hd["da_in"].data_ptr(), B, H, 1, 0, st), "da mean")
+            self._gemm(NT, hd["da_in"].data_ptr(), w0, b0, hd["da_y1"].data_ptr(), B, DA_HIDDEN, H, H, H, DA_HIDDEN, relu=True)
+            d1 = self._drop(hd["da_y1"], hd["da_d1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
+            self._gemm(NT, d1.data_ptr(), w3, b3, hd["da_logits"].data_ptr(), B, Cc, DA_HIDDEN, DA_HIDDEN, DA_HIDDEN, Cc)
+            self._chk(lib.gmp_cross_entropy_sum_fwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "da ce")
+            self._chk(lib.gmp_cross_entropy_sum_bwd(hd["da_logits"].data_ptr(), p.d64["da_labels"], B, Cc, gs, hd["da_glogits"].data_ptr(), st), "da ce bwd")
+            one = [0, B]
+            self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_glogits"].data_ptr(), d1.data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "3.weight")]),
+                                               tg, _i64([TG(ti, pre + "3.bias")]), Cc, DA_HIDDEN, 0, Cc, DA_HIDDEN, DA_HIDDEN, 1.0, 0, 0, None, 0, st), "da dW3")
+            self._gemm(NN, hd["da_glogits"].data_ptr(), w3, None, hd["da_g1"].data_ptr(), B, DA_HIDDEN, Cc, Cc, DA_HIDDEN, DA_HIDDEN)
+            self._relu_drop_bwd(hd["da_g1"], hd["da_y1"], hd["da_g1"], B * DA_HIDDEN, 100 + ti, p=self.da_dropout)
+            self._chk(lib.gmp_gemm_f32_grouped(TN, hd["da_g1"].data_ptr(), hd["da_in"].data_ptr(), None, tg, 1, _i32(one), None, None, _i64([TG(ti, pre + "0.weight")]),
+                                               tg, _i64([TG(ti, pre + "0.bias")]), DA_HIDDEN, H, 0, DA_HIDDEN, H, H, 1.0, 0, 0, None, 0, st), "da dW0")
+            self._chk(lib.gmp_gemm_f32(NN, hd["da_g1"].data_ptr(), w0, None, hd["da_gin"].data_ptr(), B, H, DA_HIDDEN, DA_HIDDEN, H, H, -lam, 0, 0, None, 0, st), "da grl")
+            g_rows = gH.data_ptr() + 4 * H * p.da_r0
+            self._chk(lib.gmp_row_gather(hd["da_gin"].data_ptr(), p.d64["da_gid"], p.d32["da_ptr"], g_rows, p.da_M, B, H, st), "da mean bwd")
 
     def _nt_xent_domains(self, ns: List[int], rows: List[int], z: Tensor, gz: Tensor, gs: int, ls: int, temperature: float, slot0: int) -> None:
         """One NT-Xent problem per domain on rows [rows[d], rows[d+1]) = [z1 ; z2]; loss sums land in scal[16+slot],
