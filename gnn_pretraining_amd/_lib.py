@@ -76,6 +76,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_bn_workspace_bytes": (sz, [i64, i32, i32, i64]),
     "gmp_bn_fwd": (C.c_int, [p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, C.POINTER(BnConfig), p, sz, p]),
     "gmp_bn_param_grads": (C.c_int, [p, i32, i32, p, p, p, p, p, i32, p]),
+    "gmp_bn_running_update_batch": (C.c_int, [i32, p, i32, p, p, p, p, p, p, p, p]),
     "gmp_bn_running_update": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p]),
     "gmp_bn_bwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, p, p, p, p, p, i32,
                              C.POINTER(BnConfig), p, sz, p]),
@@ -95,6 +96,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_sigmoid_bwd": (C.c_int, [p, p, p, i64, p]),
     "gmp_bce_sum_fwd": (C.c_int, [p, p, i64, p, p, sz, p]),
     "gmp_bce_sum_bwd": (C.c_int, [p, p, p, p, i64, p]),
+    "gmp_sigmoid_bce_sum_fwd_bwd": (C.c_int, [p, p, i64, p, p, p, p, p, sz, p]),
     "gmp_cross_entropy_sum_fwd": (C.c_int, [p, p, i64, i32, p, p, sz, p]),
     "gmp_cross_entropy_sum_bwd": (C.c_int, [p, p, i64, i32, p, p, p]),
     "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),

@@ -500,6 +500,78 @@ extern "C" int gmp_bn_running_update(const int32_t* seg_ptr, const int32_t* seg_
     return gmp::check_launch("bn_running_kernel");
 }
 
+// Several BatchNorms' running statistics in ONE launch (the 11 of a pre-training step): blockIdx.y = entry.  Per entry the
+// arithmetic is bn_running_kernel's (segments folded in order), so the results are bit-identical to separate calls.
+namespace {
+constexpr int RUN_MAX = 16;
+struct BnRunBatch {
+    int n, S;
+    float eps, momentum;
+    const int* seg_ptr;
+    float* rm[RUN_MAX];
+    float* rv[RUN_MAX];
+    const float* mean[RUN_MAX];
+    const float* rstd[RUN_MAX];
+    const int* seg_group[RUN_MAX];
+    int C[RUN_MAX];
+};
+__global__ __launch_bounds__(THREADS) void bn_running_batch_kernel(const BnRunBatch b) {
+    const int e = blockIdx.y, c = blockIdx.x * THREADS + threadIdx.x, C = b.C[e];
+    if (c >= C) return;
+    const float m = b.momentum;
+    float* rmp = b.rm[e];
+    float* rvp = b.rv[e];
+    const float* mp = b.mean[e];
+    const float* rp = b.rstd[e];
+    const int* sg = b.seg_group[e];
+    if (!sg) {
+        float rm = rmp[c], rv = rvp[c];
+        for (int s = 0; s < b.S; ++s) {
+            const int n = b.seg_ptr[s + 1] - b.seg_ptr[s];
+            if (n <= 0) continue;
+            const float mean = mp[(int64_t)s * C + c], rstd = rp[(int64_t)s * C + c];
+            const float var = 1.f / (rstd * rstd) - b.eps;
+            rm = (1.f - m) * rm + m * mean;
+            rv = (1.f - m) * rv + m * (n > 1 ? var * ((float)n / (float)(n - 1)) : var);
+        }
+        rmp[c] = rm;
+        rvp[c] = rv;
+        return;
+    }
+    for (int s = 0; s < b.S; ++s) {
+        const int n = b.seg_ptr[s + 1] - b.seg_ptr[s];
+        if (n <= 0) continue;
+        const int64_t o = (int64_t)sg[s] * C + c;
+        const float mean = mp[(int64_t)s * C + c], rstd = rp[(int64_t)s * C + c];
+        const float var = 1.f / (rstd * rstd) - b.eps;
+        const float unb = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+        rmp[o] = (1.f - m) * rmp[o] + m * mean;
+        rvp[o] = (1.f - m) * rvp[o] + m * unb;
+    }
+}
+}  // namespace
+
+extern "C" int gmp_bn_running_update_batch(int count, const int32_t* seg_ptr, int S, const int32_t* const* seg_group, const int32_t* channels,
+                                           float* const* running_mean, float* const* running_var, const float* const* save_mean,
+                                           const float* const* save_rstd, const gmp_bn_config* cfg, gmp_stream_t stream) {
+    if (!cfg || count < 1 || count > RUN_MAX || S < 0 || !seg_ptr || !channels || !running_mean || !running_var || !save_mean || !save_rstd)
+        return gmp::fail(GMP_ERR_ARG, "bn_running_update_batch: bad argument (count=%d, max %d)", count, RUN_MAX);
+    if (S == 0) return GMP_OK;
+    BnRunBatch b{};
+    b.n = count; b.S = S; b.eps = cfg->eps; b.momentum = cfg->momentum; b.seg_ptr = seg_ptr;
+    int maxC = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!running_mean[i] || !running_var[i] || !save_mean[i] || !save_rstd[i] || channels[i] <= 0)
+            return gmp::fail(GMP_ERR_ARG, "bn_running_update_batch: entry %d", i);
+        b.rm[i] = running_mean[i]; b.rv[i] = running_var[i]; b.mean[i] = save_mean[i]; b.rstd[i] = save_rstd[i];
+        b.seg_group[i] = seg_group ? seg_group[i] : nullptr;
+        b.C[i] = channels[i];
+        if (channels[i] > maxC) maxC = channels[i];
+    }
+    hipLaunchKernelGGL(bn_running_batch_kernel, dim3((maxC + THREADS - 1) / THREADS, count), dim3(THREADS), 0, (hipStream_t)stream, b);
+    return gmp::check_launch("bn_running_batch_kernel");
+}
+
 extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const int32_t* seg_ptr,
                           const int32_t* seg_group, int S, int64_t max_seg_rows, int64_t rows, int C, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var, const float* save_mean,

@@ -71,6 +71,24 @@ __global__ __launch_bounds__(T) void bce_bwd_kernel(const float* __restrict__ p,
         gp[i] = g * (p[i] - y[i]) / fmaxf((1.f - p[i]) * p[i], 1e-12f);
 }
 
+// sigmoid -> BCE(sum) -> d/dp -> d/dx in one pass (the link-prediction scorer's tail, heads.py:67 + tasks.py:120): the
+// arithmetic of sigmoid_kernel, bce_part_kernel, bce_bwd_kernel and sigmoid_bwd_kernel in that order, element by element,
+// so the numbers are those of the four separate launches
+__global__ __launch_bounds__(T) void sigmoid_bce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gs,
+                                                        float* __restrict__ p_out, float* __restrict__ gx, int64_t n, float* part) {
+    const float g = gs[0];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < n; i += (int64_t)gridDim.x * T) {
+        const float p = 1.f / (1.f + expf(-x[i]));
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(log1pf(-p), -100.f);
+        s -= y[i] * lp + (1.f - y[i]) * lq;
+        const float gp = g * (p - y[i]) / fmaxf((1.f - p) * p, 1e-12f);
+        gx[i] = gp * p * (1.f - p);
+        if (p_out) p_out[i] = p;
+    }
+    block_sum_store(s, part);
+}
+
 // one wave per row: loss_m = logsumexp(logits[m,:]) - logits[m,target]; probs optional output
 __global__ __launch_bounds__(T) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t M, int C,
                                                     float* __restrict__ rowloss, float* __restrict__ gl, const float* __restrict__ gs) {
@@ -161,6 +179,16 @@ extern "C" int gmp_bce_sum_bwd(const float* p, const float* labels, const float*
     if (!p || !labels || !g_scale || !g_p) return gmp::fail(GMP_ERR_ARG, "bce_sum_bwd: null pointer");
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(parts_for(n)), dim3(T), 0, st, p, labels, g_scale, g_p, n);
     return gmp::check_launch("bce_bwd_kernel");
+}
+extern "C" int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, int64_t n, const float* g_scale, float* loss, float* p_out,
+                                          float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    GMP_CHECK_N("sigmoid_bce_sum_fwd_bwd")
+    if (!loss || !g_scale || !ws || ws_bytes < MAX_PARTS * sizeof(float) || (n > 0 && (!x || !labels || !g_x)))
+        return gmp::fail(GMP_ERR_ARG, "sigmoid_bce_sum_fwd_bwd: bad argument");
+    const int parts = parts_for(n);
+    hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(parts), dim3(T), 0, st, x, labels, g_scale, p_out, g_x, n, (float*)ws);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(T), 0, st, (const float*)ws, parts, loss);
+    return gmp::check_launch("sigmoid_bce kernels");
 }
 extern "C" int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t M, int C, float* loss, void* ws,
                                          size_t ws_bytes, gmp_stream_t stream) {

@@ -134,21 +134,17 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             float* ld1 = drop(d, t.lp_y1, t.lp_d1, K * H, t.lp_site, st, &rc);
             GMP_TRY(rc);
             GMP_TRY(gemm(GMP_GEMM_NT, ld1, w3, b3, t.lp_y2, K, 1, H, H, H, 1, false, st));
-            GMP_TRY(gmp_sigmoid_fwd(t.lp_y2, t.lp_p, K, st));
-            GMP_TRY(gmp_bce_sum_fwd(t.lp_p, t.lp_labels, K, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
-            GMP_TRY(gmp_bce_sum_bwd(t.lp_p, t.lp_labels, t.g_scale, t.lp_gp, K, st));
-            GMP_TRY(gmp_sigmoid_bwd(t.lp_gp, t.lp_p, t.lp_gy2, K, st));
+            GMP_TRY(gmp_sigmoid_bce_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
             const int32_t one[2] = {0, (int32_t)K};
             const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3};
             GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy2, ld1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, 1, H, 0, 1, H, H, 1.f, 0, 0,
                                          t.gemm_ws, t.gemm_ws_bytes, st));
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy2, w3, nullptr, t.lp_gy1, K, H, 1, 1, H, H, false, st));
             GMP_TRY(gmp_relu_dropout_bwd(t.lp_gy1, t.lp_y1, t.lp_gy1, K * H, d.training ? d.dropout_p : 0.f, d.seed, t.lp_site, st));
-            size_t wsb = gmp_gemm_f32_workspace_bytes(GMP_GEMM_TN, H, 3 * H, K);
-            if (wsb > (size_t)K * 3 * H * sizeof(float)) wsb = 0;     // lp_gfeat doubles as the split-K scratch before it is written
-            GMP_TRY(gmp_gemm_f32(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg + t.lp_tg_w0, H, 3 * H, K, H, 3 * H, 3 * H, 1.f, 0, 0,
-                                 wsb ? t.lp_gfeat : nullptr, wsb, st));
-            GMP_TRY(gmp_colsum(t.lp_gy1, tg + t.lp_tg_b0, K, H, H, 0, t.loss_ws, t.loss_ws_bytes, st));
+            // dW0 with db0 riding along (column sums of the A tile already in LDS)
+            const int64_t cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
+                                         1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy1, w0, nullptr, t.lp_gfeat, K, 3 * H, H, H, 3 * H, 3 * H, false, st));
             GMP_TRY(gmp_lp_edge_features_bwd(t.lp_gfeat, hL, t.lp_edges, t.lp_ghs, t.lp_ghd, N, K, H, st));
             float* g_rows = gH + (int64_t)H * t.row0;
@@ -295,12 +291,19 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     if (defer) {          // running statistics of the 11 BatchNorms: off the critical path, on aux while the heads start
         (void)hipStreamWaitEvent(aux, ev[3], 0);
         c = bn_cfg(d, true, false, 0);
-        GMP_TRY(gmp_bn_running_update(d.seg_ptr, d.seg_dom, d.S, H, d.enc_rm, d.enc_rv, d.enc_mean, d.enc_rstd, &c, aux_));
+        constexpr int NB = 2 * GMP_STEP_LAYERS + 1;
+        const int32_t* sg[NB];
+        int32_t ch[NB];
+        float *rm[NB], *rv[NB];
+        const float *sm[NB], *sr[NB];
+        sg[0] = d.seg_dom; ch[0] = H; rm[0] = d.enc_rm; rv[0] = d.enc_rv; sm[0] = d.enc_mean; sr[0] = d.enc_rstd;
         for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
             const gmp_layer_desc& L = d.layer[l];
-            GMP_TRY(gmp_bn_running_update(d.seg_ptr, nullptr, d.S, 2 * H, L.rm1, L.rv1, L.m1, L.s1, &c, aux_));
-            GMP_TRY(gmp_bn_running_update(d.seg_ptr, nullptr, d.S, H, L.rm2, L.rv2, L.m2, L.s2, &c, aux_));
+            const int a = 1 + 2 * l, b = 2 + 2 * l;
+            sg[a] = nullptr; ch[a] = 2 * H; rm[a] = L.rm1; rv[a] = L.rv1; sm[a] = L.m1; sr[a] = L.s1;
+            sg[b] = nullptr; ch[b] = H; rm[b] = L.rm2; rv[b] = L.rv2; sm[b] = L.m2; sr[b] = L.s2;
         }
+        GMP_TRY(gmp_bn_running_update_batch(NB, d.seg_ptr, d.S, sg, ch, rm, rv, sm, sr, &c, aux_));
         (void)hipEventRecord(ev[NEV - 1], aux);
     }
     // heads on other streams first (their chains are the long ones: they start while main is still being fed), the ones packed

@@ -887,22 +887,16 @@ class StepEngine:
             self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
             d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
             self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
-            self._chk(lib.gmp_sigmoid_fwd(self.lp_y2.data_ptr(), self.lp_p.data_ptr(), K, st), "sigmoid")
-            self._chk(lib.gmp_bce_sum_fwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), K, ls, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "bce")
-            self._chk(lib.gmp_bce_sum_bwd(self.lp_p.data_ptr(), self.lp_lab.data_ptr(), gs, self.lp_gp.data_ptr(), K, st), "bce bwd")
-            self._chk(lib.gmp_sigmoid_bwd(self.lp_gp.data_ptr(), self.lp_p.data_ptr(), self.lp_gy2.data_ptr(), K, st), "sigmoid bwd")
+            self._chk(lib.gmp_sigmoid_bce_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
+                                                      self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "sigmoid+bce")
             one = [0, K]
             self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],
                          tg, [TG(ti, "heads.link_pred.predictor.mlp.3.bias")], 1, H, 0, 1, H, H)
             self._gemm(NN, self.lp_gy2.data_ptr(), w3, None, hd["lp_gy1"].data_ptr(), K, H, 1, 1, H, H)
             self._relu_drop_bwd(hd["lp_gy1"], hd["lp_y1"], hd["lp_gy1"], K * H, 100 + ti)
-            wsb = lib.gmp_gemm_f32_workspace_bytes(TN, H, 3 * H, K)
-            if wsb > self.hd["lp_gfeat"].numel() * 4:
-                wsb = 0
-            self._chk(lib.gmp_gemm_f32(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.weight"),
-                                       H, 3 * H, K, H, 3 * H, 3 * H, 1.0, 0, 0, hd["lp_gfeat"].data_ptr() if wsb else None, wsb, st), "lp dW0")
-            self._chk(lib.gmp_colsum(hd["lp_gy1"].data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.0.bias"), K, H, H, 0,
-                                     self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "lp db0")
+            # dW0 with db0 riding along (column sums of the A tile already in LDS)
+            self._gemm_g(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg, one, None, None,
+                         [TG(ti, "heads.link_pred.predictor.mlp.0.weight")], tg, [TG(ti, "heads.link_pred.predictor.mlp.0.bias")], H, 3 * H, 0, H, 3 * H, 3 * H)
             self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
             self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
                                                    hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")

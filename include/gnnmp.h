@@ -190,6 +190,12 @@ int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, co
 int gmp_bn_running_update(const int32_t* seg_ptr, const int32_t* seg_group, int num_segments, int channels,
                           float* running_mean, float* running_var, const float* save_mean, const float* save_rstd,
                           const gmp_bn_config* cfg, gmp_stream_t stream);
+/* The same for `count` (<= 16) BatchNorms that share seg_ptr, in one launch: HOST arrays of device pointers / channel counts
+ * (seg_group: NULL, or per entry NULL / device int32 [S]). */
+int gmp_bn_running_update_batch(int count, const int32_t* seg_ptr, int num_segments, const int32_t* const* seg_group,
+                                const int32_t* channels, float* const* running_mean, float* const* running_var,
+                                const float* const* save_mean, const float* const* save_rstd, const gmp_bn_config* cfg,
+                                gmp_stream_t stream);
 /* backward: given g_y, the BN input u = x (+ residual, recomputed on the fly), saved stats.
  *   g_u [rows,C]   gradient w.r.t. the BN input (also the residual's gradient)
  *   g_gamma/g_beta: per GRADIENT group sums (<= 24 groups, one launch); group g covers segments
@@ -281,6 +287,10 @@ int gmp_bce_sum_fwd(const float* p, const float* labels, int64_t numel, float* l
                     size_t workspace_bytes, gmp_stream_t stream);
 int gmp_bce_sum_bwd(const float* p, const float* labels, const float* g_scale, float* g_p, int64_t numel,
                     gmp_stream_t stream);
+/* sigmoid_fwd + bce_sum_fwd + bce_sum_bwd + sigmoid_bwd in one pass over the scores x (same arithmetic, element by element):
+ * loss = BCE(sigmoid(x), labels) summed, g_x = d (g_scale * loss) / d x; p_out (nullable) receives sigmoid(x). */
+int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, int64_t numel, const float* g_scale, float* loss,
+                                float* p_out, float* g_x, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t rows, int classes,
                               float* loss, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 int gmp_cross_entropy_sum_bwd(const float* logits, const int64_t* target, int64_t rows, int classes,

@@ -351,3 +351,69 @@ def test_nt_xent_grouped_equals_the_single_problem_calls(ns):
         touched[offs[g]:offs[g] + 2 * n] = True
     assert abs(float(total) - want_total) <= 1e-5 * max(abs(want_total), 1.0)
     assert float(gz[~touched.to(DEV)].abs().max() if (~touched).any() else 0.0) == 0.0
+
+
+def test_fused_sigmoid_bce_equals_the_four_separate_kernels():
+    import ctypes as C
+    from gnn_pretraining_amd import _lib as L
+    gen = torch.Generator().manual_seed(5)
+    n = 7937
+    x = (torch.randn(n, generator=gen) * 6).to(DEV)                  # saturating scores too
+    x[:3] = torch.tensor([-120.0, 120.0, 0.0])
+    y = (torch.rand(n, generator=gen) < 0.5).float().to(DEV)
+    gs = torch.tensor([1.0 / n], device=DEV)
+    l = L.lib()
+    st = ops._stream(x)
+    ws = torch.empty(l.gmp_loss_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    loss, p, gx = torch.empty(1, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    L.check(l.gmp_sigmoid_bce_sum_fwd_bwd(ops._ptr(x), ops._ptr(y), n, ops._ptr(gs), ops._ptr(loss), ops._ptr(p), ops._ptr(gx), ops._ptr(ws), ws.numel(), st), "fused")
+    p2, gp, gx2, loss2 = torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(1, device=DEV)
+    L.check(l.gmp_sigmoid_fwd(ops._ptr(x), ops._ptr(p2), n, st), "s")
+    L.check(l.gmp_bce_sum_fwd(ops._ptr(p2), ops._ptr(y), n, ops._ptr(loss2), ops._ptr(ws), ws.numel(), st), "b")
+    L.check(l.gmp_bce_sum_bwd(ops._ptr(p2), ops._ptr(y), ops._ptr(gs), ops._ptr(gp), n, st), "bb")
+    L.check(l.gmp_sigmoid_bwd(ops._ptr(gp), ops._ptr(p2), ops._ptr(gx2), n, st), "sb")
+    assert torch.equal(p, p2) and torch.equal(gx, gx2) and torch.equal(loss, loss2)
+    assert bool(torch.isfinite(gx).all()) and bool(torch.isfinite(loss).all())
+    want = torch.nn.functional.binary_cross_entropy(torch.sigmoid(x.cpu()), y.cpu(), reduction="sum")
+    close(loss, want.reshape(1), what="sigmoid+bce loss")
+
+
+def test_bn_split_entry_points_equal_the_inline_ones():
+    """gmp_bn_fwd without running stats + gmp_bn_running_update(_batch), and gmp_bn_bwd with 0 groups + gmp_bn_param_grads,
+    give bit-identical results to the all-in-one calls (the step executor uses the split forms off its critical path)."""
+    import ctypes as C
+    from gnn_pretraining_amd import _lib as L
+    gen = torch.Generator().manual_seed(9)
+    S_, Cc = 6, 512
+    sizes = torch.tensor([40, 0, 300, 17, 64, 129])
+    ptr = torch.zeros(S_ + 1, dtype=torch.int32); ptr[1:] = sizes.cumsum(0)
+    N = int(ptr[-1]); mx = int(sizes.max()); ptr = ptr.to(DEV)
+    x, g = torch.randn(N, Cc, generator=gen).to(DEV), torch.randn(N, Cc, generator=gen).to(DEV)
+    gam, bet = (torch.rand(Cc, generator=gen) + 0.5).to(DEV), (torch.randn(Cc, generator=gen) * 0.1).to(DEV)
+    rm0, rv0 = torch.randn(Cc, generator=gen).to(DEV), (torch.rand(Cc, generator=gen) + 0.5).to(DEV)
+    cfg = ops.make_bn_config(True, True)
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    y_a, sm, sr = ops.bn_fwd(x, None, ptr, mx, gam, bet, rm_a, rv_a, cfg)                       # inline running update
+    y_b, sm_b, sr_b = ops.bn_fwd(x, None, ptr, mx, gam, bet, None, None, cfg)                   # deferred
+    l, st = L.lib(), ops._stream(x)
+    rm_b, rv_b = rm0.clone(), rv0.clone()
+    L.check(l.gmp_bn_running_update(ops._ptr(ptr), None, S_, Cc, ops._ptr(rm_b), ops._ptr(rv_b), ops._ptr(sm_b), ops._ptr(sr_b), C.byref(cfg), st), "ru")
+    rm_c, rv_c = rm0.clone(), rv0.clone()
+    P = C.c_void_p
+    L.check(l.gmp_bn_running_update_batch(1, ops._ptr(ptr), S_, None, (C.c_int32 * 1)(Cc), (P * 1)(rm_c.data_ptr()), (P * 1)(rv_c.data_ptr()),
+                                          (P * 1)(sm_b.data_ptr()), (P * 1)(sr_b.data_ptr()), C.byref(cfg), st), "rub")
+    live = (sizes > 0).to(DEV)                                         # an empty segment leaves its statistics rows unwritten
+    assert torch.equal(y_a, y_b) and torch.equal(sm[live], sm_b[live]) and torch.equal(sr[live], sr_b[live])
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and torch.equal(rm_a, rm_c) and torch.equal(rv_a, rv_c)
+    assert not torch.equal(rm_a, rm0)
+    groups = [0, 2, 3, 6]
+    gu_a, gg_a, gb_a = ops.bn_bwd(g, x, None, ptr, mx, gam, bet, None, None, sm, sr, cfg, groups)
+    G = len(groups) - 1
+    ws = torch.empty(l.gmp_bn_workspace_bytes(N, Cc, S_, mx), dtype=torch.uint8, device=DEV)
+    gu_b = torch.empty_like(x)
+    gg_b, gb_b = torch.empty(G, Cc, device=DEV), torch.empty(G, Cc, device=DEV)
+    arr = (C.c_int32 * (G + 1))(*groups)
+    L.check(l.gmp_bn_bwd(ops._ptr(g), ops._ptr(x), None, ops._ptr(ptr), None, S_, mx, N, Cc, ops._ptr(gam), ops._ptr(bet), None, None, ops._ptr(sm), ops._ptr(sr),
+                         ops._ptr(gu_b), None, None, None, None, None, 0, C.byref(cfg), ops._ptr(ws), ws.numel(), st), "bwd0")
+    L.check(l.gmp_bn_param_grads(ops._ptr(ws), S_, Cc, ops._ptr(gg_b), ops._ptr(gb_b), C.cast(arr, C.c_void_p), None, None, G, st), "pg")
+    assert torch.equal(gu_a, gu_b) and torch.equal(gg_a, gg_b) and torch.equal(gb_a, gb_b)
