@@ -31,10 +31,10 @@ hipEvent_t* events() {   // one process drives one engine: a small static pool o
 // phase timing (diagnostic, GMP_STEP_TIMING=1): events on the main stream at step start / forward done / heads joined /
 // backward done, read back by gmp_step_phase_ms
 hipEvent_t* phase_events() {
-    static hipEvent_t ev[4];
+    static hipEvent_t ev[GMP_STEP_PHASES + 1];
     static bool made = false;
     if (!made) {
-        for (int i = 0; i < 4; ++i) (void)hipEventCreate(&ev[i]);
+        for (int i = 0; i <= GMP_STEP_PHASES; ++i) (void)hipEventCreate(&ev[i]);
         made = true;
     }
     return ev;
@@ -269,6 +269,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_row_fill(d.h[0], t.idx, d.flat + d.off_mask_token, t.num_idx, N, H, 1, main_));
     }
     (void)hipStreamWaitEvent(main, ev[1], 0);
+    if (timing) (void)hipEventRecord(phase_events()[1], main);
 
     // ---- stacked backbone forward
     for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
@@ -282,12 +283,13 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, defer ? nullptr : L.rm2,
                            defer ? nullptr : L.rv2, L.m2, L.s2, d.h[l + 1], &c, d.bn_ws, d.bn_ws_bytes, main_));
+        if (timing && l + 1 < GMP_STEP_LAYERS) (void)hipEventRecord(phase_events()[2 + l], main);
     }
 
     // ---- task heads, each on its own stream
     if (hipMemsetAsync(d.gA, 0, (size_t)N * H * sizeof(float), main) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step: memset");
     (void)hipEventRecord(ev[3], main);
-    if (timing) (void)hipEventRecord(phase_events()[1], main);
+    if (timing) (void)hipEventRecord(phase_events()[1 + GMP_STEP_LAYERS], main);
     if (defer) {          // running statistics of the 11 BatchNorms: off the critical path, on aux while the heads start
         (void)hipStreamWaitEvent(aux, ev[3], 0);
         c = bn_cfg(d, true, false, 0);
@@ -321,7 +323,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
     (void)hipStreamWaitEvent(main, ev[2], 0);
     if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved statistics
-    if (timing) (void)hipEventRecord(phase_events()[2], main);
+    if (timing) (void)hipEventRecord(phase_events()[2 + GMP_STEP_LAYERS], main);
 
     // ---- stacked backbone backward: per-task parameter gradients from ONE pass.
     // The input-gradient chain (BN bwd -> dgrad GEMM -> BN bwd -> dgrad GEMM -> aggregation bwd) is the critical path;
@@ -365,6 +367,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
+        if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
     }
     float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
     for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
@@ -385,16 +388,25 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
                                 d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
     }
-    if (timing) (void)hipEventRecord(phase_events()[3], main);
+    if (timing) (void)hipEventRecord(phase_events()[GMP_STEP_PHASES], main);
     return GMP_OK;
 }
 
 extern "C" int gmp_step_phase_ms(float* out3) {
     if (!out3) return gmp::fail(GMP_ERR_ARG, "step_phase_ms: null pointer");
-    if (!phase_timing()) return gmp::fail(GMP_ERR_UNSUPPORTED, "step_phase_ms: set GMP_STEP_TIMING=1 before the first step");
+    float all[GMP_STEP_PHASES];
+    if (int rc = gmp_step_phase_detail_ms(all)) return rc;
+    out3[0] = out3[1] = out3[2] = 0.f;
+    for (int i = 0; i < GMP_STEP_PHASES; ++i) out3[i <= GMP_STEP_LAYERS ? 0 : (i == GMP_STEP_LAYERS + 1 ? 1 : 2)] += all[i];
+    return GMP_OK;
+}
+
+extern "C" int gmp_step_phase_detail_ms(float* out) {
+    if (!out) return gmp::fail(GMP_ERR_ARG, "step_phase_detail_ms: null pointer");
+    if (!phase_timing()) return gmp::fail(GMP_ERR_UNSUPPORTED, "step_phase_detail_ms: set GMP_STEP_TIMING=1 before the first step");
     hipEvent_t* e = phase_events();
-    if (hipEventSynchronize(e[3]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_ms: no step recorded");
-    for (int i = 0; i < 3; ++i)
-        if (hipEventElapsedTime(&out3[i], e[i], e[i + 1]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_ms: elapsed");
+    if (hipEventSynchronize(e[GMP_STEP_PHASES]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_detail_ms: no step recorded");
+    for (int i = 0; i < GMP_STEP_PHASES; ++i)
+        if (hipEventElapsedTime(&out[i], e[i], e[i + 1]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_detail_ms: elapsed");
     return GMP_OK;
 }

@@ -122,6 +122,10 @@ int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* desc, gmp_stream_t main, cons
  * done, heads joined and backward done; this waits for the last one and returns the three phase durations in ms
  * (forward, heads, backward) of the most recent step. */
 int gmp_step_phase_ms(float* out3);
+/* The same in GMP_STEP_PHASES intervals: encoders (incl. the wait for the CSR build), forward layers 0..4, heads, backward
+ * layers 4..0, below-backbone tail (mask token + encoder backward). */
+#define GMP_STEP_PHASES (2 * GMP_STEP_LAYERS + 3)
+int gmp_step_phase_detail_ms(float* out);
 
 #ifdef __cplusplus
 }

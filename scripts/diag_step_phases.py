@@ -34,4 +34,8 @@ for k in range(80):
             acc[i] += out[i]
         t_all += (t1 - t0) * 1e3
         n += 1
+det = (C.c_float * 13)()
+L.check(L.lib().gmp_step_phase_detail_ms(det), "detail")
+print("last step detail (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f" % (
+    det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3))
 print(os.environ.get("GMP_HEAD_LAYOUT", "packed"), "forward %.3f heads %.3f backward %.3f ms | whole synchronous step %.3f ms" % (acc[0] / n, acc[1] / n, acc[2] / n, t_all / n))
