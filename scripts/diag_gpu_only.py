@@ -1,5 +1,6 @@
 """GPU time of the s4 step with the host taken out: one prepared step is re-enqueued back to back (no draw / plan / upload)."""
 import os, sys, time
+os.environ.setdefault("GMP_STEP_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as B
@@ -29,6 +30,12 @@ for reps in (100, 300):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     print(f"{reps} re-enqueued steps: GPU {a.elapsed_time(b) / reps:.3f} ms/step, host enqueue {(t1 - t0) / reps * 1e3:.3f} ms/step")
+    import ctypes as C
+    from gnn_pretraining_amd import _lib as L
+    det = (C.c_float * 13)()
+    L.check(L.lib().gmp_step_phase_detail_ms(det), "detail")
+    print("  last step, steady state (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f | sum %.0f" % (
+        det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3, sum(det) * 1e3))
 
 # where the host time goes
 import ctypes as C
