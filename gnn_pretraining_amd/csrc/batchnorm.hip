@@ -526,13 +526,23 @@ __global__ __launch_bounds__(THREADS) void bn_running_batch_kernel(const BnRunBa
     const int* sg = b.seg_group[e];
     if (!sg) {
         float rm = rmp[c], rv = rvp[c];
-        for (int s = 0; s < b.S; ++s) {
-            const int n = b.seg_ptr[s + 1] - b.seg_ptr[s];
-            if (n <= 0) continue;
-            const float mean = mp[(int64_t)s * C + c], rstd = rp[(int64_t)s * C + c];
-            const float var = 1.f / (rstd * rstd) - b.eps;
-            rm = (1.f - m) * rm + m * mean;
-            rv = (1.f - m) * rv + m * (n > 1 ? var * ((float)n / (float)(n - 1)) : var);
+        for (int s0 = 0; s0 < b.S; s0 += 8) {           // 8 segments' statistics in flight, folded in order
+            float mean[8], rstd[8];
+            int n[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u;
+                n[u] = s < b.S ? b.seg_ptr[s + 1] - b.seg_ptr[s] : 0;
+                mean[u] = n[u] > 0 ? mp[(int64_t)s * C + c] : 0.f;
+                rstd[u] = n[u] > 0 ? rp[(int64_t)s * C + c] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (n[u] <= 0) continue;
+                const float var = 1.f / (rstd[u] * rstd[u]) - b.eps;
+                rm = (1.f - m) * rm + m * mean[u];
+                rv = (1.f - m) * rv + m * (n[u] > 1 ? var * ((float)n[u] / (float)(n[u] - 1)) : var);
+            }
         }
         rmp[c] = rm;
         rvp[c] = rv;
