@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # (profiles/r01_pmc_aggregate_stream.csv): FETCH_SIZE 1,352,746 KB x 2 (gfx950 reports half of wide coalesced reads,
 # MI355X_MICROARCH.md section HBM) + WRITE_SIZE 2,146,816 KB, x 1024.  PMC passes cannot run inside this process.
 PMC_SHAPE = (2146816, 8068480)
-PMC_TRAFFIC_BYTES = int((1235049.5 * 2 + 2147475.5) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv (FETCH_SIZE x2: gfx950 correction)
+PMC_TRAFFIC_BYTES = int((1229698.6 * 2 + 2147421.6) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv (FETCH_SIZE x2: gfx950 correction)
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
 
 

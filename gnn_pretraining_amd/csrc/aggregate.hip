@@ -371,11 +371,12 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
     if (feat == 256 && N >= 65536) {          // working set beyond the caches: streaming kernel
-        // GMP_AGG_VARIANT (tuning aid): 5 = LDS-resident 128-row tiles, 1024 threads, 1 block/CU (default); 6 = 64-row
+        // GMP_AGG_VARIANT (tuning aid): 12 = LDS-resident 144-row tiles, 1024 threads, 1 block/CU (default: 153 KB of the
+        // 160 KB LDS); 5 = 128-row tiles; 6 = 64-row
         // tiles, 512 threads, 2 blocks/CU; 8 = 5 with plain stores; cache-resident predecessors: 0 = 1024 threads /
         // 256-row tiles / nt stores, 1 = same with plain stores, 2 = 512-row tiles, 3 = 512 threads / 128-row tiles,
         // 4 = 512 threads / 256-row tiles.  GMP_AGG_BLOCKS = grid
-        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 5;
+        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 12;
         static const int blocks_env = getenv("GMP_AGG_BLOCKS") ? atoi(getenv("GMP_AGG_BLOCKS")) : 0;
         hipStream_t st = (hipStream_t)stream;
 #define GMP_STREAM(SBV, TILEV, NTV, DEFBLOCKS)                                                                        \
@@ -405,6 +406,7 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
         switch (variant) {
             case 5: GMP_LDSTILE(1024, 128, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 6: GMP_LDSTILE(512, 64, 1024, true, 512); return gmp::check_launch("gin_aggregate_ldstile_kernel");
+            case 12: GMP_LDSTILE(1024, 144, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 8: GMP_LDSTILE(1024, 128, 2048, false, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 1: GMP_STREAM(1024, 256, false, 512); break;
             case 2: GMP_STREAM(1024, 512, true, 512); break;
