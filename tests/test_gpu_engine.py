@@ -293,3 +293,43 @@ def test_engine_ragged_step_losses_and_task_gradients(rng_mode):
     for k, v in osd.items():
         if "running_" in k:
             assert_close(hsd[k], v, 1e-4, f"buffer {k}")
+
+
+def test_engine_step_matches_the_committed_oracle_fixture():
+    """The same seeded s4 step as tests/golden/oracle_step.json (generated by the CPU oracle with ITS OWN draws from
+    Generator(123)): the engine, drawing with the reference-order host code from an equal generator state, must land on the
+    committed losses, touch the same parameters and move them to the same place."""
+    import json
+    import os
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_step.json")))
+    tasks, domains = PT.ACTIVE_TASKS["s4"], PT.PRETRAIN_DOMAINS["s4"]
+    torch.manual_seed(want["seed"])
+    gen = torch.Generator().manual_seed(want["seed"])
+    om = OM.PretrainableGNN(torch.device("cpu"), domains, tasks)           # same initialisation stream as the generator script
+    hm = PretrainableGNN(torch.device("cpu"), domains, tasks)
+    copy_state(hm, om)
+    before = {k: v.clone() for k, v in om.state_dict().items()}
+    hm.device = DEV
+    hm.to(DEV)
+    hm.train()
+    eng = StepEngine(hm, tasks, domains, DEV, seed=1, rng_mode="reference")
+    eng.dropout_p = 0.0
+    host = S.pretrain_step_batches(gen, domains)
+    assert {d: b.num_nodes for d, b in host.items()} == want["nodes"]
+    eng.lr.mul_(want["lr_scale"])
+    eng.temperature = OTr.TemperatureScheduler(462 * 50)()
+    eng.step(StepInputs(host, DEV, eng.dpad), gen, order=list(want["order"]))
+    got = eng.losses()
+    for k, v in want["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * abs(v), (k, got[k], v)
+    conf, proj = eng.metrics.tolist()
+    assert abs(proj - want["pcgrad"]["gradient_surgery/total_projections"]) <= 0.02 * want["pcgrad"]["gradient_surgery/total_projections"]
+    after = hm.state_dict()
+    for k, v in want["param_sq_sum_after"].items():
+        a, b0 = float((after[k].double() ** 2).sum()), float((before[k].double() ** 2).sum())
+        moved_want = abs(v - b0) > 1e-9 * max(abs(b0), 1e-12)
+        moved_got = abs(a - b0) > 1e-9 * max(abs(b0), 1e-12)
+        assert moved_got == moved_want, f"{k}: moved {moved_got} vs fixture {moved_want}"
+        assert abs(a - v) <= 2e-3 * max(abs(v), 1e-6), (k, a, v)
+    for k, v in want["running_mean_sum_after"].items():
+        assert abs(float(after[k].double().sum()) - v) <= 1e-3 * max(abs(v), 1e-2), k

@@ -417,3 +417,34 @@ def test_bn_split_entry_points_equal_the_inline_ones():
                          ops._ptr(gu_b), None, None, None, None, None, 0, C.byref(cfg), ops._ptr(ws), ws.numel(), st), "bwd0")
     L.check(l.gmp_bn_param_grads(ops._ptr(ws), S_, Cc, ops._ptr(gg_b), ops._ptr(gb_b), C.cast(arr, C.c_void_p), None, None, G, st), "pg")
     assert torch.equal(gu_a, gu_b) and torch.equal(gg_a, gg_b) and torch.equal(gb_a, gb_b)
+
+
+def test_gin_aggregate_full_size_properties():
+    """The roofline rung (65,536 graphs: 2.1 M rows, x = 2.2 GB) is too large for the CPU oracle to finish in seconds; at that size
+    the kernel is held to two size-independent identities of GINConv's sum aggregation (gnn.py:29):
+      * column checksum: sum_r out[r,:] = sum_u x[u,:] * ((1 + eps) + #times u is a neighbour)   (float64 accumulation)
+      * linearity:        agg(a*x + y) = a*agg(x) + agg(y)."""
+    from gnn_pretraining_amd.graph import Batch
+    gen = torch.Generator().manual_seed(7)
+    base = Batch.from_data_list([S.random_graph(gen, 4) for _ in range(1024)])
+    reps, n0, e0 = 64, base.num_nodes, base.num_edges
+    N, E = n0 * reps, e0 * reps
+    ei = base.edge_index.to(DEV)
+    ei_big = (ei.view(2, 1, e0) + (torch.arange(reps, device=DEV) * n0).view(1, reps, 1)).reshape(2, E).contiguous()
+    csr = ops.csr_build(ei_big, N)
+    del ei_big
+    eps = torch.tensor([0.3], device=DEV)
+    x = torch.randn(N, 256, device=DEV)
+    out = ops.gin_aggregate_fwd(x, csr.rowptr, csr.col, eps)
+    w = (1.0 + 0.3) + torch.bincount(csr.col.long(), minlength=N).double()
+    want = (x.double() * w[:, None]).sum(0)
+    got = out.double().sum(0)
+    scale = (x.double().abs() * w[:, None]).sum(0)                   # magnitude summed per column (the sums themselves cancel)
+    assert float(((got - want).abs() / scale).max()) < 1e-6
+    y = torch.randn(N, 256, device=DEV)
+    lhs = ops.gin_aggregate_fwd(2.5 * x + y, csr.rowptr, csr.col, eps)
+    rhs = 2.5 * out + ops.gin_aggregate_fwd(y, csr.rowptr, csr.col, eps)
+    del x, y
+    err = float((lhs - rhs).abs().max())
+    assert err < 1e-3 * float(rhs.abs().max()), err
+    assert bool(torch.isfinite(out).all())

@@ -141,3 +141,28 @@ def test_pretrain_state_dict_keys():
     assert one_layer == 264449 and sum(p.numel() for p in m.gnn_backbone.parameters()) == 1322245
     s4 = OM.PretrainableGNN(torch.device("cpu"), OM.PRETRAIN_DOMAINS, OT.SCHEMES["s4"])
     assert sum(p.numel() for p in s4.parameters()) == 3669302
+
+
+def test_oracle_step_reproduces_its_committed_fixture():
+    """tests/golden/oracle_step.json freezes the oracle's numbers for one seeded s4 step (losses, PCGrad counts, parameters
+    after the step): an edit to oracle/ that moves them is caught here, on the CPU."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(here, "make_oracle_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got, want = mod.run(), json.load(open(os.path.join(here, "oracle_step.json")))
+    assert got["nodes"] == want["nodes"] and got["edges"] == want["edges"]
+    for k, v in want["losses"].items():
+        assert abs(got["losses"][k] - v) <= 1e-5 * abs(v), k
+    # a conflict is "dot product < 0": pairs within rounding of orthogonal flip with the BLAS thread count, so the counts
+    # (and, through the few extra projections, the updates) are only reproducible to a few percent / a few 1e-5
+    for k in ("gradient_surgery/total_conflicts", "gradient_surgery/total_projections"):
+        assert abs(got["pcgrad"][k] - want["pcgrad"][k]) <= 0.05 * want["pcgrad"][k], k
+    for k, v in want["param_sq_sum_after"].items():
+        # 1e-3: a bias in front of a BatchNorm has an analytically zero gradient; Adam turns its rounding noise into +-lr steps
+        assert abs(got["param_sq_sum_after"][k] - v) <= 1e-3 * max(abs(v), 1e-12), k
+    for k, v in want["running_mean_sum_after"].items():
+        assert abs(got["running_mean_sum_after"][k] - v) <= 1e-5 * max(abs(v), 1e-3), k
