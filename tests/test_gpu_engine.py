@@ -330,6 +330,6 @@ def test_engine_step_matches_the_committed_oracle_fixture():
         moved_want = abs(v - b0) > 1e-9 * max(abs(b0), 1e-12)
         moved_got = abs(a - b0) > 1e-9 * max(abs(b0), 1e-12)
         assert moved_got == moved_want, f"{k}: moved {moved_got} vs fixture {moved_want}"
-        assert abs(a - v) <= 2e-3 * max(abs(v), 1e-6), (k, a, v)
+        assert abs(a - v) <= 5e-3 * abs(v) + 1e-4, (k, a, v)
     for k, v in want["running_mean_sum_after"].items():
         assert abs(float(after[k].double().sum()) - v) <= 1e-3 * max(abs(v), 1e-2), k
