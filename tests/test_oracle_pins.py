@@ -80,7 +80,7 @@ def test_pcgrad_toy_model(case):
         else:
             assert p.grad is not None, n
             torch.testing.assert_close(p.grad.flatten().double(), torch.tensor(want, dtype=torch.float64),
-                                       rtol=1e-6, atol=1e-7)
+                                       rtol=2e-5, atol=1e-6)   # fp32 on another CPU rounds tanh / the dot products differently in the last bits
 
 
 def test_pcgrad_edge_cases():
@@ -91,7 +91,7 @@ def test_pcgrad_edge_cases():
         assert metrics == pytest.approx(c["metrics"])
         assert set(final) == set(c["final"])
         for k, v in c["final"].items():
-            torch.testing.assert_close(final[k].double(), torch.tensor(v, dtype=torch.float64), rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(final[k].double(), torch.tensor(v, dtype=torch.float64), rtol=2e-5, atol=1e-6)   # fp32 on another CPU rounds tanh / the dot products differently in the last bits
 
 
 @pytest.mark.parametrize("scheme", sorted(GOLD["optimizer_groups"]))
