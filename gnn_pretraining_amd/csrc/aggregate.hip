@@ -438,7 +438,7 @@ extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t
     const int F4 = feat / 4;
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
-        if (g_eps) hipMemsetAsync(g_eps, 0, sizeof(float), st);
+        if (g_eps && hipMemsetAsync(g_eps, 0, sizeof(float), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_bwd: memset");
         return GMP_OK;
     }
     Plan p = make_plan(N);

@@ -266,8 +266,8 @@ extern "C" int gmp_csr_build(const int64_t* ei, int64_t N, int64_t E, int32_t* r
         int* cl = o == 0 ? col : col_t;
         int* pm = o == 0 ? perm : perm_t;
         int* tp = tmp + (size_t)o * E;
-        hipMemsetAsync(rp, 0, (size_t)(N + 1) * 4, stream);
-        hipMemsetAsync(cur, 0, (size_t)N * 4, stream);
+        if (hipMemsetAsync(rp, 0, (size_t)(N + 1) * 4, stream) != hipSuccess || hipMemsetAsync(cur, 0, (size_t)N * 4, stream) != hipSuccess)
+            return gmp::fail(GMP_ERR_LAUNCH, "csr_build: memset");
         int gb = (int)std::min<int64_t>(gmp::cdiv(E, 256), 4096);
         if (E > 0) hipLaunchKernelGGL(hist_kernel, dim3(gb), dim3(256), 0, stream, key, other, (int)N, E, rp,
                                       o == 0 ? status : (int*)nullptr);
