@@ -10,7 +10,6 @@ from pathlib import Path
 from typing import Dict, Iterator, List, Optional
 
 import torch
-from torch import Tensor
 
 from ..graph import Batch, Data
 from .data_setup import processed_dir

@@ -15,7 +15,7 @@ Everything raises GnnmpError on CPU tensors -- there is no eager fallback.
 from __future__ import annotations
 
 import weakref
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import Tensor

@@ -11,7 +11,7 @@ inside ``loss``: sizes are known on the host from the artefacts.
 from __future__ import annotations
 
 from abc import ABC
-from typing import Dict, List, NamedTuple, Optional, Tuple
+from typing import Dict, List, NamedTuple, Tuple
 
 import numpy as np
 import torch
