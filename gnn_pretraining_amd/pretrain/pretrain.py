@@ -245,7 +245,7 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: Optiona
     from ..engine import SUPPORTED_TASKS, StepEngine
     if use_engine and all(t in SUPPORTED_TASKS for t in cfg.active_tasks):
         engine = StepEngine(model, cfg.active_tasks, cfg.pretrain_domains, dev, seed=cfg.seed, rng_mode=rng_mode,
-                            max_rows=32768, max_edges=262144)
+                            max_rows=65536, max_edges=524288)      # 8 PROTEINS-sized graphs (<= 620 nodes) x 7 passes fit
     best, stale, global_step = float("inf"), 0, [0]
     path = OUTPUT_DIR / f"model_{cfg.exp_name}_{cfg.seed}.pt"
     for epoch in range(1, epochs + 1):
