@@ -23,6 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP: RCCL peer mappings need dmabuf IPC here
+
 import torch  # noqa: E402
 
 from gnn_pretraining_amd import dist as D, ops, synthetic as S  # noqa: E402

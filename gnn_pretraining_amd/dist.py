@@ -21,6 +21,9 @@ from torch import Tensor
 def init_from_env(backend: Optional[str] = None) -> int:
     """Join the job torchrun started (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); returns world size."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the host driver on this pool only supports dmabuf IPC: without this RCCL's peer mappings fail with
+    # "hipIpcGetMemHandle: invalid argument" (it is already exported on the GPU boxes; harmless to repeat)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
