@@ -132,6 +132,7 @@ class StepEngine:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
         self.model, self.tasks, self.domains, self.device = model, list(tasks), list(domains), torch.device(device)
         self.T, self.D = len(self.tasks), len(self.domains)
+        self._bn_calls_dom = [0] * self.D
         self.lib = L.lib()
         self.dpad = 40 if max(DOMAIN_DIMENSIONS[d] for d in domains) <= 40 else 64
         self.max_rows, self.max_edges = max_rows, max_edges
@@ -139,6 +140,7 @@ class StepEngine:
         self.shuffle_rng = shuffle_rng
         self.grad_sync = grad_sync
         self._packed_sync = None
+        self._bn_calls = 0
         self.temperature = 0.5
         self.da_dropout = DA_DROPOUT
         self.grl_lambda = 0.0              # gradient-reversal strength of the domain-adversarial task (GRLScheduler)
@@ -653,6 +655,25 @@ class StepEngine:
         h["steps"] += 1
         self.step_count += 1
         self.last_plan = p
+        if self.model.training:                      # BatchNorm call counters (one per forward() the reference would have made)
+            lens = np.diff(p.a32["seg_ptr"])
+            dom = p.a32["seg_dom"]
+            self._bn_calls += int((lens > 0).sum())
+            for di in range(self.D):
+                self._bn_calls_dom[di] += int(((lens > 0) & (dom == di)).sum())
+
+    def flush_counters(self) -> None:
+        """Bring every BatchNorm's num_batches_tracked up to date (it only matters for the saved state_dict -- momentum is
+        fixed -- so the engine counts calls on the host and writes them when asked: pretrain() does before a checkpoint)."""
+        if self._bn_calls:
+            for l in self.model.gnn_backbone.layers:
+                l.batch_norm.num_batches_tracked += self._bn_calls
+                l.gin_conv.nn[1].num_batches_tracked += self._bn_calls
+            self._bn_calls = 0
+        for di, d in enumerate(self.domains):
+            if self._bn_calls_dom[di]:
+                self.model.input_encoders[d].batch_norm.num_batches_tracked += self._bn_calls_dom[di]
+                self._bn_calls_dom[di] = 0
 
     # ---- upload ------------------------------------------------------------------------------------
     def _upload(self, p: StepPlan, inp: StepInputs, art) -> None:

@@ -254,6 +254,8 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: Optiona
             run_training_engine(state, engine, train_loader, generator, dev, epoch, global_step, logger, max_steps=steps)
         else:
             run_training(state, train_loader, generator, dev, epoch, global_step, logger, max_steps=steps)
+        if engine is not None:
+            engine.flush_counters()
         torch.cuda.synchronize() if dev.type == "cuda" else None
         t1 = time.time()
         if engine is not None:

@@ -105,10 +105,13 @@ def test_engine_losses_task_gradients_and_running_stats(scheme, seed, rng_mode):
             if p.grad is not None:
                 assert_grad_close(eng.task_gradient(name, n), p.grad, gmax, f"{name}: grad {n}")
     # running statistics: 28 sequential updates reproduced by one stacked pass
+    eng.flush_counters()
     osd, hsd = om.state_dict(), hm.state_dict()
     for k, v in osd.items():
         if "running_" in k:
             assert_close(hsd[k], v, 1e-4, f"buffer {k}")
+        if k.endswith("num_batches_tracked"):
+            assert int(hsd[k]) == int(v), (k, int(hsd[k]), int(v))
 
 
 def test_engine_full_s4_step_matches_oracle_step():
