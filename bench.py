@@ -114,6 +114,30 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters}
 
 
+def gemm_roofline(device, rows: int = 7392):
+    """The dense feature-transform GEMM of a backbone layer at the step's size (rows of the stacked s4 batch x 256 -> 512, fp32
+    MFMA, bias epilogue) against the 157 TFLOP/s fp32 MFMA peak: HIP events on the launch stream, 50 launches."""
+    A, B = torch.randn(rows, 256, device=device), torch.randn(512, 256, device=device)
+    bias, out = torch.randn(512, device=device), torch.empty(rows, 512, device=device)
+    for _ in range(10):
+        ops.gemm(ops.NT, A, B, bias, out)
+    iters = 50
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize(device)
+    ev[0].record()
+    for _ in range(iters):
+        ops.gemm(ops.NT, A, B, bias, out)
+    ev[1].record()
+    torch.cuda.synchronize(device)
+    ms = ev[0].elapsed_time(ev[1]) / iters
+    flops = 2.0 * rows * 512 * 256
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": 157.0, "unit": "TFLOP/s", "frac": round(ach / 157.0, 4), "traffic": None,
+            "kernel": "gemm_kernel<64,64,NT> (gmp_gemm_f32: GIN layer 256 -> 512 + bias)", "M": rows, "N": 512, "K": 256,
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches": iters,
+            "note": "host-paced loop: includes the launch-to-launch gap of back-to-back dependent launches"}
+
+
 def cpu_baseline(seed: int, budget_s: float = 20.0):
     """The CPU oracle (a port: the reference itself needs torch_geometric) on this box's host cores."""
     from oracle import models as OM, tasks as OTk, train as OTr
@@ -202,10 +226,12 @@ def main() -> None:
     hm = engine.host_ms
     log(f"{a.steps} steps in {elapsed:.3f} s; last-step losses {engine.losses()}")
     log("host ms/step: " + ", ".join(f"{k} {hm[k] / max(hm['steps'], 1):.2f}" for k in ("draw", "plan", "upload", "launch")))
-    roof = cpu = None
+    roof = roof_gemm = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)
         log(f"roofline {roof['achieved']} GB/s")
+        roof_gemm = gemm_roofline(device)
+        log(f"gemm {roof_gemm['achieved']} TFLOP/s")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline ...")
         cpu = cpu_baseline(seed)
@@ -218,7 +244,7 @@ def main() -> None:
             "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
                        "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "index_rng": a.rng},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
         }
         print(json.dumps(line))
     if world > 1:
