@@ -176,11 +176,15 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
-    ap.add_argument("--rng", choices=["reference", "vectorized"], default="vectorized",
+    ap.add_argument("--rng", choices=["reference", "vectorized"], default=None,
                     help="how the step's augmentation/mask/negative indices are drawn on the host: 'reference' = the exact "
                          "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
-                         "distributions, all graphs of a domain at once (numpy)")
+                         "distributions, all graphs of a domain at once (numpy).  Default: reference when the native host module "
+                         "is built, else vectorized")
     a = ap.parse_args()
+    from gnn_pretraining_amd.engine import hostdraw
+    if a.rng is None:       # the reference's exact draw order when its native implementation is built (GPU-bound either way)
+        a.rng = "reference" if hostdraw() is not None else "vectorized"
 
     if a.roofline_only:
         torch.cuda.set_device(0)
@@ -243,7 +247,8 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
-                       "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "index_rng": a.rng},
+                       "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "index_rng": a.rng,
+                       "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy"},
             "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
         }
         print(json.dumps(line))

@@ -109,6 +109,24 @@ class ViewArrays:
         self.rows, self.edges, self.ptr, self.rowmask, self.common = rows, edges, ptr, rowmask, common
 
 
+_HOSTDRAW, _HOSTDRAW_TRIED = None, False
+
+
+def hostdraw():
+    """The native module for the reference-order draws (csrc_host/hostdraw.cpp), or None when it has not been built: the
+    Python implementations it mirrors then run instead (bit-identical, ~10x slower, and they hold the GIL)."""
+    global _HOSTDRAW, _HOSTDRAW_TRIED
+    if not _HOSTDRAW_TRIED:
+        _HOSTDRAW_TRIED = True
+        if os.environ.get("GMP_NO_HOSTDRAW") is None:
+            try:
+                from . import _hostdraw
+                _HOSTDRAW = _hostdraw
+            except ImportError:
+                _HOSTDRAW = None
+    return _HOSTDRAW
+
+
 def _empty_views():
     z, e = np.zeros(0, dtype=np.int64), np.zeros((2, 0), dtype=np.int64)
     return (ViewArrays(z, e, np.zeros(1, dtype=np.int64), None, z), ViewArrays(z.copy(), e.copy(), np.zeros(1, dtype=np.int64), None, z.copy()))
@@ -320,11 +338,19 @@ class StepEngine:
             return self._draw_vectorized(inp, gen)
         art: Dict[str, object] = {}
         host = {d: inp.host[d] for d in self.domains}
+        H = hostdraw()
+        if H is not None:
+            args = {d: (torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long), b.edge_index.contiguous())
+                    for d, b in host.items() if b.num_graphs}
         for t in self.tasks:
             if t == "node_feat_mask":
-                art[t] = {d: (draw_mask_indices(b.ptr_host, gen).numpy() if b.num_graphs else _EMPTY_ART[t]()) for d, b in host.items()}
+                art[t] = {d: (_EMPTY_ART[t]() if not b.num_graphs else
+                              H.mask_indices(args[d][0], gen).numpy() if H is not None else draw_mask_indices(b.ptr_host, gen).numpy())
+                          for d, b in host.items()}
             elif t == "link_pred":
-                art[t] = {d: (sample_negative_edges(b, gen).numpy() if b.num_graphs else _EMPTY_ART[t]()) for d, b in host.items()}
+                art[t] = {d: (_EMPTY_ART[t]() if not b.num_graphs else
+                              H.negative_edges(*args[d], gen).numpy() if H is not None else sample_negative_edges(b, gen).numpy())
+                          for d, b in host.items()}
             elif t in ("node_contrast", "graph_contrast"):
                 art[t] = {d: (_EMPTY_ART[t]() if b.num_graphs == 0 else
                               self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
@@ -333,7 +359,21 @@ class StepEngine:
 
     @staticmethod
     def _draw_views(b: Batch, gen: torch.Generator) -> Tuple[ViewArrays, ViewArrays]:
-        """Same draws as GraphAugmentor.create_two_views (augmentations.py:88-111), kept as index arrays."""
+        """Same draws as GraphAugmentor.create_two_views (augmentations.py:88-111), kept as index arrays: the native module
+        when it is built, the Python loop below otherwise (bit-identical, tests/test_hostdraw.py)."""
+        H = hostdraw()
+        if H is None:
+            return StepEngine._draw_views_python(b, gen)
+        r = H.draw_views(torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long), b.edge_index.contiguous(),
+                         int(b.x.size(1)), gen)
+        out = []
+        for vi in range(2):
+            rows, edges, vptr, rowmask, common = (t.numpy() for t in r[5 * vi:5 * vi + 5])
+            out.append(ViewArrays(rows, edges, vptr, rowmask.view(np.uint64) if rowmask.size else None, common))
+        return out[0], out[1]
+
+    @staticmethod
+    def _draw_views_python(b: Batch, gen: torch.Generator) -> Tuple[ViewArrays, ViewArrays]:
         ei = b.edge_index.numpy()
         F = b.x.size(1)
         acc = [dict(rows=[], edges=[], ptr=[0], masks=[], common=[]) for _ in range(2)]

@@ -1,0 +1,83 @@
+"""The native host module (csrc_host/hostdraw.cpp) against the Python implementation of the reference's draw order:
+for an equal generator state the index arrays are bit-identical AND the generator is left in the same state (so every
+later draw of the run -- sampler, evaluation -- is unchanged).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from gnn_pretraining_amd import synthetic as S
+from gnn_pretraining_amd.engine import StepEngine, hostdraw
+from gnn_pretraining_amd.graph import Batch, Data
+from gnn_pretraining_amd.models.pretrain_model import draw_mask_indices
+from gnn_pretraining_amd.pretrain.tasks import sample_negative_edges
+
+pytestmark = pytest.mark.skipif(hostdraw() is None, reason="gnn_pretraining_amd/_hostdraw.so not built (python -m gnn_pretraining_amd.csrc_host.build)")
+
+
+def _gens(seed):
+    a, b = torch.Generator(), torch.Generator()
+    a.manual_seed(seed); b.manual_seed(seed)
+    return a, b
+
+
+def _batches():
+    gen = torch.Generator().manual_seed(5)
+    out = [S.domain_batch(gen, d, 8) for d in (7, 4, 37, 21)]
+    out.append(S.domain_batch(gen, 2, 3))                                            # fewer than 3 features: no attribute mask possible
+    out.append(Batch.from_data_list([Data(torch.zeros(1, 4), torch.zeros(2, 0, dtype=torch.long), torch.zeros(1, dtype=torch.long), torch.zeros(12)),
+                                     Data(torch.zeros(2, 4), torch.tensor([[0, 1], [1, 0]]), torch.zeros(1, dtype=torch.long), torch.zeros(12)),
+                                     S.random_graph(gen, 4, 126.0, 200.0)]))                 # 1-node, 2-node and a large graph
+    return out
+
+
+def _args(b):
+    return torch.tensor(b.ptr_host), torch.tensor(b.edge_ptr_host), b.edge_index.contiguous()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345])
+def test_native_draws_equal_the_python_reference_order(seed):
+    H = hostdraw()
+    for b in _batches():
+        ptr, eptr, ei = _args(b)
+        g1, g2 = _gens(seed)
+        assert torch.equal(H.mask_indices(ptr, g1), draw_mask_indices(b.ptr_host, g2))
+        assert torch.equal(g1.get_state(), g2.get_state())
+        assert torch.equal(H.negative_edges(ptr, eptr, ei, g1), sample_negative_edges(b, g2))
+        assert torch.equal(g1.get_state(), g2.get_state())
+        for _ in range(3):                                                       # several rounds: coins fall differently
+            got = H.draw_views(ptr, eptr, ei, b.x.size(1), g1)
+            want = StepEngine._draw_views_python(b, g2)
+            for vi in range(2):
+                rows, edges, vptr, rowmask, common = got[5 * vi:5 * vi + 5]
+                w = want[vi]
+                assert np.array_equal(rows.numpy(), w.rows) and np.array_equal(edges.numpy(), w.edges)
+                assert np.array_equal(vptr.numpy(), w.ptr) and np.array_equal(common.numpy(), w.common)
+                if w.rowmask is None:
+                    assert rowmask.numel() == 0
+                else:
+                    assert np.array_equal(rowmask.numpy().view(np.uint64), w.rowmask)
+            assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_engine_draw_uses_the_native_module_and_matches_python(monkeypatch):
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from test_host_logic import _Inp, _planner
+    e = _planner("reference", "s4")
+    gen = torch.Generator().manual_seed(3)
+    inp = _Inp(S.pretrain_step_batches(gen, e.domains))
+    g1, g2 = _gens(9)
+    art_native = e.draw(inp, g1)
+    monkeypatch.setattr("gnn_pretraining_amd.engine._HOSTDRAW", None)
+    monkeypatch.setattr("gnn_pretraining_amd.engine._HOSTDRAW_TRIED", True)
+    art_python = e.draw(inp, g2)
+    assert torch.equal(g1.get_state(), g2.get_state())
+    for t in art_python:
+        for d in art_python[t]:
+            a, b = art_native[t][d], art_python[t][d]
+            if isinstance(b, tuple):
+                for va, vb in zip(a, b):
+                    assert all(np.array_equal(getattr(va, f), getattr(vb, f)) for f in ("rows", "edges", "ptr", "common"))
+                    assert (va.rowmask is None) == (vb.rowmask is None) and (va.rowmask is None or np.array_equal(va.rowmask, vb.rowmask))
+            else:
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (t, d)
