@@ -190,6 +190,8 @@ def main() -> None:
         torch.cuda.set_device(0)
         print(json.dumps({"roofline": aggregation_roofline(torch.device("cuda:0"))}))
         return
+    from gnn_pretraining_amd._host import limit_host_threads
+    limit_host_threads(1)      # the host side of a step is tiny index work: torch's default pool (every core of the node, per rank) only hurts
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(torch.cuda.device_count(), 1)
     device = torch.device(f"cuda:{local % ndev}")       # one rank per GPU; (rehearsals on a 1-GPU box share it over gloo)
