@@ -83,14 +83,16 @@ class StepInputs:
         for d in self.domains:
             self.row_off[d] = rows
             rows += self.host[d].num_nodes
-        x = torch.zeros(rows, dpad)
+        pin = torch.device(device).type == "cuda"
+        x = torch.zeros(rows, dpad, pin_memory=pin)           # pinned (cached by torch's host allocator): the copy below is asynchronous
         gp = []
         for d in self.domains:
             hb = self.host[d]
             x[self.row_off[d]:self.row_off[d] + hb.num_nodes, :hb.x.size(1)] = hb.x
             gp.append(hb.graph_properties.to(torch.float32).view(hb.num_graphs, GRAPH_PROPERTY_DIM))
-        self.x_all = x.to(device)
-        self.graph_props = torch.cat(gp).to(device)           # [sum B, 12] in domain order
+        self.x_all = x.to(device, non_blocking=pin)
+        g = torch.cat(gp)
+        self.graph_props = (g.pin_memory() if pin else g).to(device, non_blocking=pin)           # [sum B, 12] in domain order
 
 
 class StepPlan:
