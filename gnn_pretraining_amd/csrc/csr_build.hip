@@ -62,11 +62,24 @@ __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(
     for (int i = t; i <= N; i += SMALL_THREADS) cnt[i] = 0;
     for (int i = t; i < N; i += SMALL_THREADS) cur[i] = 0;
     __syncthreads();
+    // one workgroup walks all E edges twice: keep 8 independent (key, other) loads in flight per thread per trip, otherwise
+    // each trip is one exposed global-memory latency (30 trips x 2 passes at the step's 30k edges)
+    constexpr int U = 8;
     int bad = 0;
-    for (int e = t; e < E; e += SMALL_THREADS) {
-        int64_t k = key[e], v = other[e];
-        if (k >= 0 && k < N && v >= 0 && v < N) atomicAdd(&cnt[(int)k], 1);
-        else ++bad;
+    for (int e0 = t; e0 < E; e0 += SMALL_THREADS * U) {
+        int64_t k[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * SMALL_THREADS;
+            k[u] = e < E ? key[e] : 0;
+            v[u] = e < E ? other[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e0 + u * SMALL_THREADS >= E) continue;
+            if (k[u] >= 0 && k[u] < N && v[u] >= 0 && v[u] < N) atomicAdd(&cnt[(int)k[u]], 1);
+            else ++bad;
+        }
     }
     if (o == 0 && bad) atomicAdd(status, bad);
     __syncthreads();
@@ -91,9 +104,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void csr_small_kernel(
     }
     __syncthreads();
     for (int i = t; i <= N; i += SMALL_THREADS) rowptr[i] = cnt[i];
-    for (int e = t; e < E; e += SMALL_THREADS) {
-        int64_t k = key[e], v = other[e];
-        if (k >= 0 && k < N && v >= 0 && v < N) tmp[cnt[(int)k] + atomicAdd(&cur[(int)k], 1)] = e;
+    for (int e0 = t; e0 < E; e0 += SMALL_THREADS * U) {
+        int64_t k[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * SMALL_THREADS;
+            k[u] = e < E ? key[e] : -1;
+            v[u] = e < E ? other[e] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k[u] >= 0 && k[u] < N && v[u] >= 0 && v[u] < N) tmp[cnt[(int)k[u]] + atomicAdd(&cur[(int)k[u]], 1)] = e0 + u * SMALL_THREADS;
     }
     __threadfence_block();
     __syncthreads();
