@@ -243,7 +243,11 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // ---- CSR builds beside the encoders (they only need the uploaded indices)
     (void)hipEventRecord(ev[0], main);
     (void)hipStreamWaitEvent(aux, ev[0], 0);
-    GMP_TRY(gmp_csr_build(d.edge_index, N, d.E, d.csr[0], d.csr[1], d.csr[2], d.csr[3], d.csr[4], d.csr[5], d.csr_status, d.csr_ws, d.csr_ws_bytes, aux_));
+    if (d.max_seg <= 8192 && d.max_seg_edges <= 24576)      // block diagonal: one workgroup per (segment, orientation)
+        GMP_TRY(gmp_csr_build_segmented(d.edge_index, N, d.E, d.seg_ptr, d.seg_eptr, d.S, d.max_seg, d.max_seg_edges, d.csr[0], d.csr[1], d.csr[2], d.csr[3],
+                                        d.csr[4], d.csr[5], d.csr_status, aux_));
+    else
+        GMP_TRY(gmp_csr_build(d.edge_index, N, d.E, d.csr[0], d.csr[1], d.csr[2], d.csr[3], d.csr[4], d.csr[5], d.csr_status, d.csr_ws, d.csr_ws_bytes, aux_));
     (void)hipEventRecord(ev[1], aux);
     int lp_task = -1;
     for (int ti = 0; ti < T; ++ti)

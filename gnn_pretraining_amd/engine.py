@@ -41,6 +41,8 @@ from .pretrain.tasks import sample_negative_edges
 H = GNN_HIDDEN_DIM
 NT, NN, TN = 0, 1, 2
 MAXT = 8
+SEG_CSR_MAX_ROWS, SEG_CSR_MAX_EDGES = 8192, 24576        # gmp_csr_build_segmented: what one workgroup's LDS holds
+
 # rough length (us) of each head's kernel chain at the s4 workload, used only to balance heads over the four streams
 HEAD_CHAIN_US = {"node_contrast": 350.0, "link_pred": 330.0, "graph_contrast": 250.0, "node_feat_mask": 130.0, "graph_prop": 100.0,
                  "domain_adv": 100.0}
@@ -618,6 +620,9 @@ class StepEngine:
             raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
                                f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
         a32["seg_ptr"], a32["seg_dom"], a32["src_row"] = np.asarray(seg_ptr), np.asarray(seg_dom), np.concatenate(src_rows)
+        seg_eptr = np.concatenate([[0], np.cumsum([e.shape[1] for e in edges])])       # the batch is block diagonal: one CSR build per segment
+        a32["seg_eptr"] = seg_eptr
+        p.max_seg_edges = int(np.diff(seg_eptr).max()) if len(edges) else 0
         nt = [(b - a + 31) // 32 for a, b in zip(seg_ptr[:-1], seg_ptr[1:])]
         tile_seg = np.repeat(np.arange(p.S), nt)
         tile_first = np.concatenate([[0], np.cumsum(nt)])[:-1]
@@ -796,9 +801,14 @@ class StepEngine:
         self.aux_stream.wait_event(ev_up)
         with torch.cuda.stream(self.aux_stream):
             ast = self.aux_stream.cuda_stream
-            self._chk(lib.gmp_csr_build(p.d64["edge_index"], N, p.E, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
-                                        c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(),
-                                        self.csr_ws.numel(), ast), "csr_build")
+            if p.max_seg <= SEG_CSR_MAX_ROWS and p.max_seg_edges <= SEG_CSR_MAX_EDGES:      # block diagonal: one workgroup per segment
+                self._chk(lib.gmp_csr_build_segmented(p.d64["edge_index"], N, p.E, p.d32["seg_ptr"], p.d32["seg_eptr"], p.S, p.max_seg,
+                                                      p.max_seg_edges, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                                                      c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), ast), "csr_build_segmented")
+            else:
+                self._chk(lib.gmp_csr_build(p.d64["edge_index"], N, p.E, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                                            c[4].data_ptr(), c[5].data_ptr(), self.csr_status.data_ptr(), self.csr_ws.data_ptr(),
+                                            self.csr_ws.numel(), ast), "csr_build")
             ev_csr = torch.cuda.Event(); ev_csr.record(self.aux_stream)
             if "link_pred" in self.tasks:
                 lc = self.lp_csr
@@ -1268,6 +1278,7 @@ class StepEngine:
         d = getattr(self, "_desc", None) or self._init_desc()
         D = self.domains
         d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
+        d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
         d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
         d.seg_ptr, d.seg_dom, d.src_row, d.tiles = p.d32["seg_ptr"], p.d32["seg_dom"], p.d32["src_row"], p.d32["tiles"]

@@ -59,6 +59,16 @@ int gmp_csr_build(const int64_t* edge_index, int64_t num_nodes, int64_t num_edge
                   int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t,
                   int32_t* status, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 
+/* The same arrays for a BLOCK-DIAGONAL batch whose blocks ("segments": one forward() call's graphs) own contiguous row ranges
+ * seg_row_ptr[s]..[s+1] and contiguous edge ranges seg_edge_ptr[s]..[s+1] (device int32 [S+1]; no edge leaves its segment):
+ * one workgroup per (segment, orientation) instead of one per orientation -- the stacked batch of a pre-training step.
+ * max_seg_rows / max_seg_edges: host-side maxima (LDS sizing; GMP_ERR_UNSUPPORTED when a segment does not fit).  An edge with
+ * an endpoint outside its segment is dropped and counted in status. */
+int gmp_csr_build_segmented(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges, const int32_t* seg_row_ptr,
+                            const int32_t* seg_edge_ptr, int num_segments, int64_t max_seg_rows, int64_t max_seg_edges,
+                            int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t,
+                            int32_t* status, gmp_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * GIN neighbourhood aggregation (the SpMM-style kernel of BASELINE.json).
  *   fwd: out[i,:] = (1 + eps) * x[i,:] + sum_{k in rowptr[i]..rowptr[i+1]} x[col[k],:]

@@ -80,10 +80,12 @@ typedef struct {
 typedef struct {
     /* sizes of this step */
     int32_t N, E, S, max_seg, num_tiles, num_tasks, num_domains, dpad, training, hidden;
+    int32_t max_seg_edges;        /* largest number of edges of one segment (the batch is block diagonal: CSR is built per segment) */
     float dropout_p;
     uint64_t seed;
     /* uploaded index arrays */
     const int32_t *seg_ptr, *seg_dom, *src_row, *tiles;
+    const int32_t* seg_eptr;      /* [S+1] first edge of each segment in edge_index */
     const int64_t *edge_index, *rowmask;
     int32_t task_row[GMP_STEP_MAX_TASKS + 1];   /* host: first stacked row of each task */
     int32_t task_seg[GMP_STEP_MAX_TASKS + 1];   /* host: first segment of each task */

@@ -448,3 +448,43 @@ def test_gin_aggregate_full_size_properties():
     err = float((lhs - rhs).abs().max())
     assert err < 1e-3 * float(rhs.abs().max()), err
     assert bool(torch.isfinite(out).all())
+
+
+def test_csr_build_segmented_equals_the_whole_batch_build():
+    """Block-diagonal batches (the stacked step: one block per forward() call) get one workgroup per block; all six arrays
+    must be those of gmp_csr_build on the whole batch -- including empty blocks (domains absent from a step) and blocks of
+    isolated nodes."""
+    import ctypes as C
+    from gnn_pretraining_amd import _lib as L
+    gen = torch.Generator().manual_seed(17)
+    blocks = [S.domain_batch(gen, 4, k) for k in (8, 1, 3, 8, 32)]
+    rows, eds, seg_row, seg_edge = 0, [], [0], [0]
+    for i, b in enumerate(blocks):
+        eds.append(b.edge_index + rows)
+        rows += b.num_nodes
+        seg_row.append(rows); seg_edge.append(seg_edge[-1] + b.num_edges)
+        if i == 1:                                             # an empty block, and a block without edges (5 isolated nodes)
+            seg_row.append(rows); seg_edge.append(seg_edge[-1])
+            rows += 5
+            seg_row.append(rows); seg_edge.append(seg_edge[-1])
+    seg_row.append(rows); seg_edge.append(seg_edge[-1])        # trailing empty block
+    ei = torch.cat(eds, dim=1).contiguous().to(DEV)
+    N, E, Sg = rows, ei.size(1), len(seg_row) - 1
+    want = ops.csr_build(ei, N)
+    l, st = L.lib(), ops._stream(ei)
+    i32 = lambda n: torch.full((n,), -7, dtype=torch.int32, device=DEV)
+    out = [i32(N + 1), i32(E), i32(E), i32(N + 1), i32(E), i32(E)]
+    status = torch.ones(1, dtype=torch.int32, device=DEV)
+    sr, se = torch.tensor(seg_row, dtype=torch.int32, device=DEV), torch.tensor(seg_edge, dtype=torch.int32, device=DEV)
+    mr, me = max(b - a for a, b in zip(seg_row[:-1], seg_row[1:])), max(b - a for a, b in zip(seg_edge[:-1], seg_edge[1:]))
+    L.check(l.gmp_csr_build_segmented(ops._ptr(ei), N, E, ops._ptr(sr), ops._ptr(se), Sg, mr, me, *[ops._ptr(t) for t in out], ops._ptr(status), st), "seg")
+    assert int(status) == 0
+    for got, exp, name in zip(out, (want.rowptr, want.col, want.perm, want.rowptr_t, want.col_t, want.perm_t),
+                              ("rowptr", "col", "perm", "rowptr_t", "col_t", "perm_t")):
+        assert torch.equal(got, exp), name
+    # an edge that leaves its block is dropped and counted, never dereferenced
+    bad = ei.clone(); bad[0, 0] = N - 1
+    L.check(l.gmp_csr_build_segmented(ops._ptr(bad), N, E, ops._ptr(sr), ops._ptr(se), Sg, mr, me, *[ops._ptr(t) for t in out], ops._ptr(status), st), "seg")
+    assert int(status) == 1
+    with pytest.raises(Exception):
+        L.check(l.gmp_csr_build_segmented(ops._ptr(ei), N, E, ops._ptr(sr), ops._ptr(se), Sg, 100000, me, *[ops._ptr(t) for t in out], ops._ptr(status), st), "seg")
