@@ -51,6 +51,11 @@ struct MtArgs {
 
 __global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
     const int k = blockIdx.x, j = blockIdx.y;
+    const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
+    if (j * per >= len) {                       // small tensors fill only their first chunks: the rest contribute zeros
+        if (threadIdx.x < MAXT * MAXT) a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + threadIdx.x] = 0.0;
+        return;
+    }
     bool has[MAXT];
     int nh = 0;
 #pragma unroll
@@ -59,40 +64,60 @@ __global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
         nh += has[t];
     }
     if (nh < 2) return;                         // nothing to project against
-    const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
-    const int lo = j * per, hi = min(lo + per, len);
+    const int lo = j * per, hi = min(lo + per, (len + 3) / 4 * 4);     // slots are zero-padded to a multiple of 4 floats
     double* out = a.gram_part + ((int64_t)k * GCH + j) * (MAXT * MAXT);
     // all MAXT x MAXT upper-triangle products with compile-time indices (runtime-indexed arrays would live in scratch)
     float acc[MAXT * (MAXT + 1) / 2];
 #pragma unroll
     for (int p = 0; p < MAXT * (MAXT + 1) / 2; ++p) acc[p] = 0.f;
     const int64_t off = a.off[k];
-    for (int i = lo + threadIdx.x; i < hi; i += TB) {     // <= 16 elements per thread: fp32 partials are exact enough
-        float g[MAXT];
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 4 * TB) {     // <= 16 elements per thread: fp32 partials are exact enough
+        float4 g[MAXT];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) g[t] = has[t] ? a.tg[(int64_t)t * a.stride + off + i] : 0.f;
+        for (int t = 0; t < MAXT; ++t)
+            g[t] = has[t] ? *reinterpret_cast<const float4*>(a.tg + (int64_t)t * a.stride + off + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         int p = 0;
 #pragma unroll
         for (int x = 0; x < MAXT; ++x)
 #pragma unroll
-            for (int y = x; y < MAXT; ++y) acc[p++] += g[x] * g[y];
-    }
-    __shared__ double sh[TB];
-    int p = 0;
-#pragma unroll
-    for (int x = 0; x < MAXT; ++x)
-#pragma unroll
-        for (int y = x; y < MAXT; ++y, ++p) {
-            if (!(has[x] && has[y])) continue;            // block-uniform
-            __syncthreads();
-            sh[threadIdx.x] = (double)acc[p];
-            __syncthreads();
-            for (int d = TB / 2; d > 0; d >>= 1) {
-                if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-                __syncthreads();
+            for (int y = x; y < MAXT; ++y, ++p) {
+                if (!(has[x] && has[y])) continue;
+                acc[p] += g[x].x * g[y].x;
+                acc[p] += g[x].y * g[y].y;
+                acc[p] += g[x].z * g[y].z;
+                acc[p] += g[x].w * g[y].w;
             }
-            if (threadIdx.x == 0) out[x * MAXT + y] = sh[0];
+    }
+    // block sum of every product: butterfly inside each wave (fixed order), one barrier, then the waves' partials in wave order
+    // -- one barrier in all, where a shared-memory tree per product took sixteen for each of the fifteen products
+    constexpr int NP = MAXT * (MAXT + 1) / 2, NW = TB / 64;
+    __shared__ double sh[NW][NP];
+    const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
+    {
+        int p = 0;
+#pragma unroll
+        for (int x = 0; x < MAXT; ++x)
+#pragma unroll
+            for (int y = x; y < MAXT; ++y, ++p) {
+                if (!(has[x] && has[y])) continue;        // block-uniform: only the products of tasks that own this tensor
+                double v = (double)acc[p];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) sh[wv][p] = v;
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < NP) {
+        int x = 0, rem = threadIdx.x;                      // (x, y) of upper-triangle slot threadIdx.x
+        while (rem >= MAXT - x) { rem -= MAXT - x; ++x; }
+        const int y = x + rem;
+        if (has[x] && has[y]) {
+            double v = sh[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += sh[w][threadIdx.x];
+            out[x * MAXT + y] = v;
         }
+    }
 }
 
 // sum the chunk partials in chunk order into the symmetric Gram matrix of every tensor
@@ -202,31 +227,38 @@ __global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
     }
 }
 
+// Every tensor starts on a 16-byte boundary of the flat buffers and is padded to a multiple of 4 floats (zeros in params, in the
+// gradients and in the optimizer state, and they stay zeros), so both sweeps below move float4.
 __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
-    __shared__ float sh[TB];
+    __shared__ float sh[TB / 64];
     const int k = blockIdx.x, j = blockIdx.y;
     float ss = 0.f;
     if (a.flags[k]) {
         float w[MAXT];
         for (int t = 0; t < MAXT; ++t) w[t] = a.weights[k * MAXT + t];
-        const int len = a.len[k], per = (len + CH - 1) / CH;
-        const int lo = j * per, hi = min(lo + per, len);
+        const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+        const int lo = j * per, hi = min(lo + per, len4);
         const int64_t off = a.off[k];
         for (int i = lo + threadIdx.x; i < hi; i += TB) {
-            float g = 0.f;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int t = 0; t < a.T; ++t)
-                if (w[t] != 0.f) g = fmaf(w[t], a.tg[(int64_t)t * a.stride + off + i], g);
-            a.final_grad[off + i] = g;
-            ss = fmaf(g, g, ss);
+                if (w[t] != 0.f) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.tg + (int64_t)t * a.stride + off + 4 * (int64_t)i);
+                    g = make_float4(fmaf(w[t], v.x, g.x), fmaf(w[t], v.y, g.y), fmaf(w[t], v.z, g.z), fmaf(w[t], v.w, g.w));
+                }
+            *reinterpret_cast<float4*>(a.final_grad + off + 4 * (int64_t)i) = g;
+            ss = fmaf(g.x, g.x, ss); ss = fmaf(g.y, g.y, ss); ss = fmaf(g.z, g.z, ss); ss = fmaf(g.w, g.w, ss);
         }
     }
-    sh[threadIdx.x] = ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (threadIdx.x % 64 == 0) sh[threadIdx.x / 64] = ss;
     __syncthreads();
-    for (int d = TB / 2; d > 0; d >>= 1) {
-        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = sh[0];
+        for (int w = 1; w < TB / 64; ++w) s += sh[w];
+        a.partial[k * CH + j] = s;
     }
-    if (threadIdx.x == 0) a.partial[k * CH + j] = sh[0];
 }
 
 __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
@@ -260,18 +292,30 @@ __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
     const float lr = a.lr[k], wd = a.wd[k], step = a.steps[k];
     const float bc1 = 1.f - powf(a.beta1, step), bc2 = 1.f - powf(a.beta2, step);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
-    const int len = a.len[k], per = (len + CH - 1) / CH;
-    const int lo = j * per, hi = min(lo + per, len);
+    const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+    const int lo = j * per, hi = min(lo + per, len4);
     const int64_t off = a.off[k];
+    auto one = [&](float g, float p, float m0, float v0, float* mo, float* vo) -> float {
+        g *= coef;
+        p *= (1.f - lr * wd);
+        const float m = m0 + (g - m0) * (1.f - a.beta1);       // lerp_
+        const float v = v0 * a.beta2 + g * g * (1.f - a.beta2);
+        *mo = m;
+        *vo = v;
+        return p - step_size * (m / (sqrtf(v) / bc2s + a.eps));
+    };
     for (int i = lo + threadIdx.x; i < hi; i += TB) {
-        const float g = a.final_grad[off + i] * coef;
-        float p = a.params[off + i] * (1.f - lr * wd);
-        const float m = a.exp_avg[off + i] + (g - a.exp_avg[off + i]) * (1.f - a.beta1);       // lerp_
-        const float v = a.exp_avg_sq[off + i] * a.beta2 + g * g * (1.f - a.beta2);
-        a.exp_avg[off + i] = m;
-        a.exp_avg_sq[off + i] = v;
-        p -= step_size * (m / (sqrtf(v) / bc2s + a.eps));
-        a.params[off + i] = p;
+        const int64_t o = off + 4 * (int64_t)i;
+        const float4 g = *reinterpret_cast<const float4*>(a.final_grad + o), p = *reinterpret_cast<const float4*>(a.params + o);
+        const float4 m0 = *reinterpret_cast<const float4*>(a.exp_avg + o), v0 = *reinterpret_cast<const float4*>(a.exp_avg_sq + o);
+        float4 m, v, q;
+        q.x = one(g.x, p.x, m0.x, v0.x, &m.x, &v.x);
+        q.y = one(g.y, p.y, m0.y, v0.y, &m.y, &v.y);
+        q.z = one(g.z, p.z, m0.z, v0.z, &m.z, &v.z);
+        q.w = one(g.w, p.w, m0.w, v0.w, &m.w, &v.w);
+        *reinterpret_cast<float4*>(a.exp_avg + o) = m;
+        *reinterpret_cast<float4*>(a.exp_avg_sq + o) = v;
+        *reinterpret_cast<float4*>(a.params + o) = q;
     }
 }
 

@@ -371,6 +371,9 @@ int gmp_encoder_bwd(const float* x_all, int64_t num_x_rows, int64_t num_rows, in
  *   Tensors that end up without a gradient (flags_out[k] == 0) are skipped by AdamW entirely, including
  *   their step count, as torch.optim does for grad=None.
  *   apply_update == 0: stop after final_grad / normsq_out (unclipped) -- used by parity tests.
+ *   Layout contract (the sweeps move float4): every buffer 16-byte aligned, task_stride and every tensor_off multiples of 4,
+ *   and each tensor's slot padded to a multiple of 4 floats with zeros in params, task_grads and the optimizer state (the
+ *   padding is swept along and stays zero).
  * ------------------------------------------------------------------------- */
 size_t gmp_mt_workspace_bytes(int num_tensors);
 int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
