@@ -361,6 +361,29 @@ class StepEngine:
                           for d, b in host.items()}
         return art
 
+    DRAWN_TASKS = ("node_feat_mask", "link_pred", "node_contrast", "graph_contrast")
+
+    def draw_task(self, t: str, b: Batch, gen: torch.Generator):
+        """The reference-order draws of ONE task for ONE domain batch -- what task.compute_loss({domain: batch}, generator)
+        consumes from the generator (validation walks tasks x domains x batches in that order, pretrain.py:211-221)."""
+        if b.num_graphs == 0:
+            return _EMPTY_ART[t]()
+        H = hostdraw()
+        if t == "node_feat_mask":
+            return (H.mask_indices(torch.tensor(b.ptr_host, dtype=torch.long), gen) if H is not None else draw_mask_indices(b.ptr_host, gen)).numpy()
+        if t == "link_pred":
+            if H is None:
+                return sample_negative_edges(b, gen).numpy()
+            return H.negative_edges(torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long),
+                                    b.edge_index.contiguous(), gen).numpy()
+        if t in ("node_contrast", "graph_contrast"):
+            return self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None
+        raise KeyError(t)
+
+    @staticmethod
+    def empty_art(t: str):
+        return _EMPTY_ART[t]()
+
     @staticmethod
     def _draw_views(b: Batch, gen: torch.Generator) -> Tuple[ViewArrays, ViewArrays]:
         """Same draws as GraphAugmentor.create_two_views (augmentations.py:88-111), kept as index arrays: the native module

@@ -193,21 +193,29 @@ def _val_metrics(state: StepState, per_dt: Dict[str, Dict[str, float]]) -> Dict[
 def run_evaluation_engine(state: StepState, engine, val_loaders, generator: torch.Generator, device) -> Dict[str, float]:
     """run_evaluation on the stacked engine: one pass per validation batch computes ALL tasks' losses for that domain (the
     other domains enter as empty batches; eval mode: running statistics, no dropout, no update) instead of one module
-    forward per task -- 21 passes instead of 105 per epoch on the four-domain schemes.  The draws for a batch are made for
-    all tasks together, so the shared generator is consumed batch-major rather than the reference's task-major order
-    (its evaluation is stochastic either way, pretrain.py:218-220); the statistic computed is the same."""
+    forward per task -- 21 passes instead of 105 per epoch on the four-domain schemes.
+    With the reference's draw order (rng_mode "reference") every draw of the evaluation is made FIRST, in the reference's
+    task-major order over domains over batches (pretrain.py:211-221), and handed to the passes, so the shared generator is
+    consumed exactly as the reference consumes it; with vectorised draws each pass draws for itself."""
     from ..constants import DOMAIN_DIMENSIONS
     from ..engine import StepInputs
     from ..graph import Batch
     state.model.eval()
     tasks = list(state.tasks)
+    batches = {d: list(loader) for d, loader in val_loaders.items()}
+    arts = None
+    if engine.rng_mode == "reference":
+        arts = {t: {d: [engine.draw_task(t, b, generator) for b in batches[d]] for d in batches} for t in tasks if t in engine.DRAWN_TASKS}
     per_dt: Dict[str, Dict[str, float]] = {}
-    for d, loader in val_loaders.items():
+    for d in batches:
         acc = {t: [] for t in tasks}
-        for b in loader:
+        for k, b in enumerate(batches[d]):
             host = {x: (b if x == d else Batch.empty(DOMAIN_DIMENSIONS[x])) for x in engine.domains}
+            art = None
+            if arts is not None:
+                art = {t: {x: (arts[t][d][k] if x == d else engine.empty_art(t)) for x in engine.domains} for t in arts}
             engine.temperature, engine.grl_lambda = state.temperature(), state.grl()
-            engine.step(StepInputs(host, device, engine.dpad), generator, apply_update=False)
+            engine.step(StepInputs(host, device, engine.dpad), generator, art=art, apply_update=False)
             for t, v in engine.losses().items():
                 acc[t].append(v)
         per_dt[d] = {t: sum(v) / len(v) for t, v in acc.items()}

@@ -336,3 +336,28 @@ def test_engine_step_matches_the_committed_oracle_fixture():
         assert abs(a - v) <= 5e-3 * abs(v) + 1e-4, (k, a, v)
     for k, v in want["running_mean_sum_after"].items():
         assert abs(float(after[k].double().sum()) - v) <= 1e-3 * max(abs(v), 1e-2), k
+
+
+def test_engine_validation_consumes_the_generator_like_the_reference_loop(tmp_path):
+    """pretrain.py:193-281 evaluates task by task, domain by domain, batch by batch, drawing from the shared generator as it
+    goes.  The engine evaluates batch by batch for all tasks at once; in reference-RNG mode it makes the draws first, in the
+    reference's order.  Same generator state afterwards (so the next training epoch sees the same stream) and the same
+    validation metrics as the per-task module loop."""
+    from gnn_pretraining_amd.data import data_setup as DS
+    from gnn_pretraining_amd.data.pretrain_data_loaders import create_val_data_loader
+    DS.process_synthetic(tmp_path, scale=0.05)
+    cfg = PT.PretrainConfig("s4", 3)
+    torch.manual_seed(3)
+    hm = PretrainableGNN(DEV, cfg.pretrain_domains, cfg.active_tasks)
+    state = PT.StepState(hm, cfg, steps_per_epoch=10, epochs=2)
+    eng = StepEngine(hm, cfg.active_tasks, cfg.pretrain_domains, DEV, seed=3, rng_mode="reference", max_rows=65536, max_edges=524288)
+    g0 = torch.Generator().manual_seed(11)
+    loaders = {d: create_val_data_loader(d, g0, tmp_path) for d in cfg.pretrain_domains}
+    ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    m_mod = PT.run_evaluation(state, loaders, ga, DEV)
+    state.balancer.step_count -= 1                                   # both calls advance the warm-up counter once
+    m_eng = PT.run_evaluation_engine(state, eng, loaders, gb, DEV)
+    assert torch.equal(ga.get_state(), gb.get_state())
+    assert set(m_mod) == set(m_eng)
+    for k, v in m_mod.items():
+        assert abs(m_eng[k] - v) <= 2e-4 * max(abs(v), 1e-3), (k, m_eng[k], v)
