@@ -29,8 +29,11 @@ def init_from_env(backend: Optional[str] = None) -> int:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend)
+            local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))   # binds the communicator to this rank's GPU
+        else:
+            dist.init_process_group(backend=backend)
     return world
 
 
