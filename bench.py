@@ -182,13 +182,25 @@ def main() -> None:
                          "distributions, all graphs of a domain at once (numpy).  Default: reference when the native host module "
                          "is built, else vectorized")
     a = ap.parse_args()
+    # Only the result line may reach stdout: RCCL prints a banner (HIP / ROCm version, hostname, library path) on stdout when a
+    # communicator is created, on every rank.  Everything printed before the result goes to stderr instead.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: dict) -> None:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
+
     from gnn_pretraining_amd.engine import hostdraw
     if a.rng is None:       # the reference's exact draw order when its native implementation is built (GPU-bound either way)
         a.rng = "reference" if hostdraw() is not None else "vectorized"
 
     if a.roofline_only:
         torch.cuda.set_device(0)
-        print(json.dumps({"roofline": aggregation_roofline(torch.device("cuda:0"))}))
+        emit({"roofline": aggregation_roofline(torch.device("cuda:0"))})
         return
     from gnn_pretraining_amd._host import limit_host_threads
     limit_host_threads(1)      # the host side of a step is tiny index work: torch's default pool (every core of the node, per rank) only hurts
@@ -253,7 +265,7 @@ def main() -> None:
                        "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy"},
             "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
         }
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         torch.distributed.barrier()                 # rank 0 may still be in its roofline leg: leave together
         torch.distributed.destroy_process_group()
