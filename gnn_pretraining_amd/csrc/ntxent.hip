@@ -250,28 +250,29 @@ __global__ __launch_bounds__(THREADS) void row_loss_grouped_kernel(float* __rest
     if (threadIdx.x == 0) rowloss[(int64_t)grp * Rm + i] = lse - sp;
 }
 
-// one block: per-group loss sums (same tree as sum_rows_kernel over the group's R rows) and their total in group order
-__global__ __launch_bounds__(THREADS) void loss_sums_grouped_kernel(const float* __restrict__ rowloss, NtxGroups g, float* __restrict__ sums,
+// one block: per-group loss sums and their total in group order.  Wave w reduces group w (butterfly over the lanes' strided partial
+// sums: a fixed order), so the groups are summed side by side and one barrier is enough.
+__global__ __launch_bounds__(MAXG * 64) void loss_sums_grouped_kernel(const float* __restrict__ rowloss, NtxGroups g, float* __restrict__ sums,
                                                                     float* __restrict__ total) {
-    __shared__ float sh[THREADS];
-    float tot = 0.f;
-    for (int grp = 0; grp < g.G; ++grp) {
+    __shared__ float sh[MAXG];
+    const int grp = threadIdx.x / 64, lane = threadIdx.x % 64;
+    float s = 0.f;
+    if (grp < g.G) {
         const int64_t R = 2 * (int64_t)g.n[grp];
-        float s = 0.f;
-        for (int64_t i = threadIdx.x; i < R; i += THREADS) s += rowloss[(int64_t)grp * g.Rmax + i];
-        __syncthreads();
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int d = THREADS / 2; d > 0; d >>= 1) {
-            if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            if (sums) sums[grp] = sh[0];
-            tot += sh[0];
-        }
+        for (int64_t i = lane; i < R; i += 64) s += rowloss[(int64_t)grp * g.Rmax + i];
     }
-    if (threadIdx.x == 0 && total) total[0] = tot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) sh[grp] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < g.G; ++k) {
+            if (sums) sums[k] = sh[k];
+            tot += sh[k];
+        }
+        if (total) total[0] = tot;
+    }
 }
 
 __global__ __launch_bounds__(THREADS) void normalize_bwd_grouped_kernel(const float* __restrict__ zn, const float* __restrict__ norm,
@@ -338,7 +339,7 @@ extern "C" int gmp_nt_xent_grouped(const float* z, float* g_z, int groups, const
     if (int rc = gmp_gemm_f32_grouped(GMP_GEMM_NT, w.zn, w.zn, nullptr, w.Gm, groups, rows, off_zn, nullptr, nullptr, nullptr, nullptr, 0, Rm, d,
                                       d, d, Rm, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;
     hipLaunchKernelGGL(row_loss_grouped_kernel, dim3((unsigned)Rm, groups), dim3(THREADS), 0, st, w.Gm, g, w.rowloss);
-    hipLaunchKernelGGL(loss_sums_grouped_kernel, dim3(1), dim3(THREADS), 0, st, (const float*)w.rowloss, g, loss_sums, loss_total);
+    hipLaunchKernelGGL(loss_sums_grouped_kernel, dim3(1), dim3(MAXG * 64), 0, st, (const float*)w.rowloss, g, loss_sums, loss_total);
     // d loss / d zn = (G + G^T) zn / T, the two halves into gzn / gzn2
     if (int rc = gmp_gemm_f32_grouped(GMP_GEMM_NN, w.Gm, w.zn, nullptr, w.gzn, groups, rows, off_zn, nullptr, nullptr, nullptr, nullptr, 0, d, Rm,
                                       Rm, d, d, 1.f / T, 0, 0, nullptr, 0, stream)) return rc;

@@ -267,8 +267,8 @@ int gmp_relu_dropout_bwd(const float* g, const float* act, float* out, int64_t n
 /* Grouped form: the per-domain problems of one contrastive task (tasks.py:192-213, 265-287 loop over domains) in 7 launches
  * instead of 7 per domain; forward and backward in one call.  Group g's 2*n_host[g] rows [z1; z2] start at row
  * row_off_host[g] of z [*, dim] and its gradient goes to the same rows of g_z; loss_sums[g] (nullable) receives the group's
- * loss sum, loss_total (nullable) their sum in group order.  groups <= 8; n may be 0 for a group.  Per group the numbers
- * are those of gmp_nt_xent_fwd / _bwd (zero padding adds nothing). */
+ * loss sum, loss_total (nullable) their sum in group order.  groups <= 8; n may be 0 for a group.  Per group the gradients
+ * are bit for bit those of gmp_nt_xent_fwd / _bwd (zero padding adds nothing); the loss sums add the same row losses in another order. */
 size_t gmp_nt_xent_grouped_workspace_bytes(int groups, int64_t max_n, int dim);
 int gmp_nt_xent_grouped(const float* z, float* g_z, int groups, const int32_t* n_host, const int64_t* row_off_host, int dim,
                         float temperature, const float* g_scale, float* loss_sums, float* loss_total, void* workspace,

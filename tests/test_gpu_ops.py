@@ -326,7 +326,7 @@ def test_nt_xent(n, d, T):
 @pytest.mark.parametrize("ns", [[8, 8, 8, 8], [201, 0, 37, 150], [1, 5], [0, 0, 0]])
 def test_nt_xent_grouped_equals_the_single_problem_calls(ns):
     """the per-domain problems of a contrastive task in one call: per group the loss sum and the gradient are those of
-    gmp_nt_xent_fwd/_bwd on that group alone (zero padding adds nothing) -- held bit-exact"""
+    gmp_nt_xent_fwd/_bwd on that group alone (zero padding adds nothing): gradients bit-exact, loss sums to summation order"""
     gen = torch.Generator().manual_seed(sum(ns) + len(ns))
     d, T = 128, 0.37
     offs, rows = [], 3                                   # leading rows that belong to no group
@@ -345,7 +345,7 @@ def test_nt_xent_grouped_equals_the_single_problem_calls(ns):
         z1, z2 = z[offs[g]:offs[g] + n].contiguous(), z[offs[g] + n:offs[g] + 2 * n].contiguous()
         loss, ws = ops.nt_xent_fwd(z1, z2, T)
         g1, g2 = ops.nt_xent_bwd(z1, z2, T, gs, ws)
-        assert torch.equal(sums[g:g + 1], loss), f"group {g} loss"
+        assert abs(float(sums[g]) - float(loss)) <= 1e-6 * abs(float(loss)), f"group {g} loss"      # same rows, another summation order
         assert torch.equal(gz[offs[g]:offs[g] + n], g1) and torch.equal(gz[offs[g] + n:offs[g] + 2 * n], g2), f"group {g} gradient"
         want_total += float(loss)
         touched[offs[g]:offs[g] + 2 * n] = True
