@@ -17,7 +17,7 @@ constexpr int THREADS = 256;
 constexpr int COLS = 64;          // columns per block
 constexpr int CQ = COLS / 4;      // float4 column quads per block (16)
 constexpr int RL = THREADS / CQ;  // row lanes per block (16)
-constexpr int SHORT_MAX = 512;
+constexpr int SHORT_MAX = 1024;
 constexpr int CHUNK = 256;        // rows per chunk in the long regime
 
 struct BnArgs {
@@ -116,8 +116,11 @@ __device__ __forceinline__ float4 colsum_t(float4 v, float4 (*sh)[CQ_], int rl, 
     return s;
 }
 
-template <int RPT>
-__global__ __launch_bounds__(THREADS) void bn_fwd_short_kernel(BnArgs a) {
+// RL row lanes per column quad: 32 (256 threads, segments up to 16 * 32 = 512 rows) or 64 (512 threads, up to 1,024 rows: the
+// 32-graph segments of the single-domain scheme and of validation batches stay in this one-read regime)
+template <int RPT, int RL = SRL>
+__global__ __launch_bounds__(RL * SCQ) void bn_fwd_short_kernel(BnArgs a) {
+    constexpr int SRL = RL;          // shadows the 32-lane default below
     __shared__ float4 sh[SRL][SCQ];
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
     const int c = blockIdx.y * SCOLS + cq * 4;
@@ -299,8 +302,9 @@ __device__ __forceinline__ float4 gate_of(const BnArgs& a, float4 xh, float4 gam
 // Register-resident like the forward, but only the normalised inputs stay in registers (RPT float4): the upstream gradient is
 // read twice (second time out of L2) and the gate is recomputed.  Keeping both operands resident needed 256 VGPRs at
 // RPT = 16 -- one wave per SIMD, nothing to hide a load behind -- and made this the slowest kernel of the backward chain.
-template <int RPT>
-__global__ __launch_bounds__(THREADS) void bn_bwd_short_kernel(BnArgs a) {
+template <int RPT, int RL = SRL>
+__global__ __launch_bounds__(RL * SCQ) void bn_bwd_short_kernel(BnArgs a) {
+    constexpr int SRL = RL;
     __shared__ float4 sh[SRL][SCQ];
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
     const int c = blockIdx.y * SCOLS + cq * 4;
@@ -447,7 +451,8 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
     do {                                                                               \
         if ((MAXROWS) <= 4 * SRL) hipLaunchKernelGGL(KERNEL<4>, GRID, BLK, 0, ST, ARGS);      \
         else if ((MAXROWS) <= 8 * SRL) hipLaunchKernelGGL(KERNEL<8>, GRID, BLK, 0, ST, ARGS); \
-        else hipLaunchKernelGGL(KERNEL<16>, GRID, BLK, 0, ST, ARGS);                   \
+        else if ((MAXROWS) <= 16 * SRL) hipLaunchKernelGGL(KERNEL<16>, GRID, BLK, 0, ST, ARGS); \
+        else hipLaunchKernelGGL((KERNEL<16, 2 * SRL>), GRID, dim3(2 * SRL * SCQ), 0, ST, ARGS);  \
     } while (0)
 
 extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group, int S,
