@@ -103,12 +103,15 @@ _SIGS: Dict[str, tuple] = {
     "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),
     "gmp_hard_negative_workspace_bytes": (sz, [i64, i64]),
     "gmp_hard_negative_topk": (C.c_int, [p, i64, i64, p, i64, i64, p, p, p, p, sz, p]),
+    "gmp_streams_share_queue": (C.c_int, [p, p, p]),
+    "gmp_spin_us": (C.c_int, [i32, p]),
     "gmp_segments_pack": (C.c_int, [p, p, p, i32, i64, p]),
     "gmp_segments_unpack": (C.c_int, [p, p, p, i32, i64, f32, p]),
     "gmp_encoder_fwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, p, p, p, i32, p, p]),
     "gmp_encoder_bwd": (C.c_int, [p, i64, i64, i32, p, p, p, p, p, i32, p, i32, i32, p, p, p, p, p, sz, p]),
     "gmp_step_desc_size": (sz, []),
     "gmp_pretrain_step_fwd_bwd": (C.c_int, [p, p, p, p]),
+    "gmp_step_wait_grads": (C.c_int, [i32, p]),
     "gmp_step_phase_ms": (C.c_int, [p]),
     "gmp_step_phase_detail_ms": (C.c_int, [p]),
     "gmp_mt_workspace_bytes": (sz, [i32]),

@@ -41,6 +41,12 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def _exchange_needed() -> bool:
+    """False on a single rank -- unless GMP_DP_FORCE=1 asks for the pack / all-reduce / unpack sequence anyway
+    (scripts/diag_dp_overlap.py: what the exchange machinery costs a step on one GPU)."""
+    return world_size() > 1 or (dist.is_initialized() and os.environ.get("GMP_DP_FORCE") == "1")
+
+
 def rank() -> int:
     return dist.get_rank() if dist.is_initialized() else 0
 
@@ -103,7 +109,7 @@ class PackedGradSync:
 
     def average_(self) -> None:
         w = world_size()
-        if w == 1 or self.total == 0:
+        if not _exchange_needed() or self.total == 0:
             return
         L = self._L
         st = torch.cuda.current_stream(self.base.device).cuda_stream
@@ -112,3 +118,31 @@ class PackedGradSync:
         dist.all_reduce(self.packed, op=dist.ReduceOp.SUM)
         L.check(L.lib().gmp_segments_unpack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total,
                                             1.0 / w, st), "gmp_segments_unpack")
+
+
+class OverlappedGradSync:
+    """The exchange of the stacked engine run BESIDE the stacked backward (libgnnmp
+    gmp_step_wait_grads).  The per-task gradient matrix is cut into parts in the order the step finishes them -- the task
+    heads (final before the backward starts), then backbone layers 4 ... 1, then layer 0 + mask token + encoders -- and
+    every part is packed, all-reduced and written back on `comm` (one of the engine's two head streams, idle during the
+    backward: the runtime has four hardware queues and the step already uses four streams, so no new stream is created)
+    as soon as the events of that part have fired.  Only the last part (about 6 of 36 MB for s4) is exposed after the
+    backward; RCCL runs a synchronous collective on the caller's current stream, so every collective is ordered behind
+    its own pack kernel and before its unpack kernel without host involvement.  The result is bitwise the one-message
+    exchange: the same elementwise sums, only sent in pieces."""
+
+    def __init__(self, base: Tensor, parts, comm: "torch.cuda.Stream") -> None:
+        self.parts = [PackedGradSync(base, slices) for slices in parts]
+        self.comm = comm
+        self.total = sum(p.total for p in self.parts)
+
+    def average_(self, lib, main: "torch.cuda.Stream") -> None:
+        if not _exchange_needed():
+            return
+        from . import _lib as L
+        with torch.cuda.stream(self.comm):
+            handle = self.comm.cuda_stream
+            for b, part in enumerate(self.parts):
+                L.check(lib.gmp_step_wait_grads(b, handle), "gmp_step_wait_grads")
+                part.average_()
+        main.wait_stream(self.comm)

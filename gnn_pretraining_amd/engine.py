@@ -276,8 +276,11 @@ class StepEngine:
         # slower), and a per-task stream layout left three task heads serialised on one queue (profiles/README.md).  So:
         # exactly four streams -- main, aux and two more -- and the heads are packed onto them by estimated chain length
         # (longest first onto the least-loaded stream; main and aux are idle while the heads run).
-        self.aux_stream = torch.cuda.Stream(device=dev)
-        extra = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # ... and which hardware queue a stream lands on is measured, not assumed (streams.py): a kernel trace showed two of the
+        # four streams sharing the main stream's queue, their heads running behind main's instead of beside them.
+        from .streams import concurrent_streams
+        self.aux_stream, *extra = concurrent_streams(dev, 3)
+        self.comm_stream = extra[1]        # data-parallel exchange beside the backward (the head streams are idle by then)
         bins = [[0.0, extra[0]], [0.0, extra[1]], [0.0, self.aux_stream], [0.0, None]]      # None = the main stream
         self.task_streams = [None] * self.T
         if os.environ.get("GMP_HEAD_LAYOUT") == "per_task":                 # A/B aid: the old one-stream-per-task layout
@@ -1177,14 +1180,39 @@ class StepEngine:
 
     def _sync_task_grads(self) -> None:
         """Data parallel: average the per-task gradients over ranks BEFORE PCGrad -- shared tensors once per task,
-        every head once (only its own task's row is meaningful) -- in one flat all-reduce."""
+        every head once (only its own task's row is meaningful).  Native executor: in parts beside the backward
+        (dist.OverlappedGradSync; GMP_DP_OVERLAP=0 falls back to one flat all-reduce after it)."""
+        head_slices = []
         if self._packed_sync is None:
-            from .dist import PackedGradSync
-            slices = [(t * self.P, self.P_shared) for t in range(self.T)]
             for k, n in enumerate(self.names):
                 if n.startswith("heads."):
                     t = int(np.argmax(self.has_static[k]))
-                    slices.append((t * self.P + self.off[n], -(-self.numel[n] // 4) * 4))       # tensors are 4-float aligned
+                    head_slices.append((t * self.P + self.off[n], -(-self.numel[n] // 4) * 4))       # tensors are 4-float aligned
+        if self.native and os.environ.get("GMP_DP_OVERLAP", "1") != "0":
+            if self._packed_sync is None:
+                from .dist import OverlappedGradSync
+                # shared tensors by the part of the backward that finishes them: layer l >= 1 -> part L - l, the rest -> part L
+                ranges: List[List[List[int]]] = [[] for _ in range(GNN_NUM_LAYERS + 1)]
+                shared = [n for n in self.names if self.off[n] < self.P_shared]
+                for i, n in enumerate(shared):
+                    part = GNN_NUM_LAYERS
+                    if n.startswith("gnn_backbone.layers."):
+                        l = int(n.split(".")[2])
+                        part = GNN_NUM_LAYERS - l if l >= 1 else GNN_NUM_LAYERS
+                    end = self.off[shared[i + 1]] if i + 1 < len(shared) else self.P_shared
+                    r = ranges[part]
+                    if r and r[-1][1] == self.off[n]:
+                        r[-1][1] = end                                   # contiguous with the previous tensor of this part
+                    else:
+                        r.append([self.off[n], end])
+                parts = [head_slices] + [[(t * self.P + lo, hi - lo) for t in range(self.T) for lo, hi in ranges[b]]
+                                         for b in range(1, GNN_NUM_LAYERS + 1)]
+                self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
+            self._packed_sync.average_(self.lib, torch.cuda.current_stream(self.device))
+            return
+        if self._packed_sync is None:
+            from .dist import PackedGradSync
+            slices = [(t * self.P, self.P_shared) for t in range(self.T)] + head_slices
             self._packed_sync = PackedGradSync(self.task_grads.view(-1), slices)
         self._packed_sync.average_()
 

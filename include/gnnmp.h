@@ -339,6 +339,16 @@ int gmp_segments_unpack(float* base, const float* packed, const int64_t* table_d
                         gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Streams and hardware queues (no reference counterpart: the reference runs everything on one stream).  The runtime maps a
+ * process's HIP streams onto a few hardware queues (4 by default) and packets of one queue run in order, so two streams on
+ * the same queue never overlap.  gmp_streams_share_queue MEASURES it: a 400 us spin kernel on `a`, an empty kernel on `b`;
+ * *share_host = 1 when b's kernel only finished with a's (same queue, or a == b), 0 when it ran beside it.  Synchronises both
+ * streams (start-up calibration, not a per-step call).  gmp_spin_us enqueues the busy-wait kernel (diagnostics).
+ * ------------------------------------------------------------------------- */
+int gmp_streams_share_queue(gmp_stream_t a, gmp_stream_t b, int* share_host);
+int gmp_spin_us(int microseconds, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one
  * launch.  Features of all domains sit padded to `dpad` (<= 64) columns in x_all [R, dpad]; stacked row
  * r reads x_all[src_row[r]]; segment s belongs to domain seg_dom[s] (weights at params + w_off_host[d],

@@ -120,6 +120,12 @@ size_t gmp_step_desc_size(void);
  * aux: stream for the CSR builds (may equal main). */
 int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* desc, gmp_stream_t main, const gmp_stream_t* task_streams,
                               gmp_stream_t aux);
+/* Data-parallel exchange beside the backward: make `stream` wait until the per-task gradients of one part of
+ * the model are final in task_grads for the most recent gmp_pretrain_step_fwd_bwd of this process.  part 0: the task heads
+ * (final before the stacked backward starts); part 1 + k: backbone layer GMP_STEP_LAYERS-1-k; part GMP_STEP_LAYERS: layer 0,
+ * mask token and input encoders (end of the backward).  The caller then packs / all-reduces that part on `stream` while
+ * the backward of the layers below is still running. */
+int gmp_step_wait_grads(int part, gmp_stream_t stream);
 /* Diagnostic: with GMP_STEP_TIMING=1 in the environment the call above records events on `main` at step start, forward
  * done, heads joined and backward done; this waits for the last one and returns the three phase durations in ms
  * (forward, heads, backward) of the most recent step. */

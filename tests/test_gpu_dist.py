@@ -38,8 +38,8 @@ def _inputs(rank, eng):
     return StepInputs(S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"]), eng.device, eng.dpad), gen
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GMP_DP_OVERLAP=overlap)
     import torch.distributed as dist
     from gnn_pretraining_amd import dist as D
     D.init_from_env("gloo")
@@ -47,15 +47,53 @@ def _worker(rank, world, port, out):
     inp, gen = _inputs(rank, eng)
     eng.step(inp, gen)
     torch.cuda.synchronize()
-    out[rank] = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu()}
+    first = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu()}
+    eng.step(inp, gen)                                                      # a second step: the events / message buffers are reused
+    torch.cuda.synchronize()
+    sync = eng._packed_sync
+    parts = [list(zip(p.table[:p.n].tolist(), (p.table[p.n + 1:] - p.table[p.n:-1]).tolist())) for p in getattr(sync, "parts", [sync])]
+    out[rank] = dict(first, flat2=eng.flat.cpu(), parts=parts, kind=type(sync).__name__)
     dist.destroy_process_group()
 
 
-def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical():
+@pytest.fixture(scope="module")
+def flat_exchange():
+    """The one-message exchange after the backward (GMP_DP_OVERLAP=0): the result the overlapped one must reproduce bitwise."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out, "0"), nprocs=world, join=True)
+    return {r: out[r] for r in range(world)}
+
+
+def test_overlapped_exchange_sends_the_same_slices_and_gives_the_same_bits(flat_exchange):
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out, "1"), nprocs=world, join=True)
+    assert out[0]["kind"] == "OverlappedGradSync" and flat_exchange[0]["kind"] == "PackedGradSync"
+    assert len(out[0]["parts"]) == 6                                        # heads, layers 4..1, layer 0 + mask token + encoders
+    cover = lambda parts: sorted((o, n) for part in parts for (o, n) in part)
+    def merged(sl):                                                         # union of half-open float ranges
+        res = []
+        for o, n in sl:
+            if res and res[-1][1] == o:
+                res[-1][1] = o + n
+            else:
+                assert not res or res[-1][1] < o, "slices overlap"
+                res.append([o, o + n])
+        return res
+    assert merged(cover(out[0]["parts"])) == merged(cover(flat_exchange[0]["parts"]))
+    for r in range(world):
+        for key in ("tg", "flat", "flat2"):
+            assert torch.equal(out[r][key], flat_exchange[r][key]), key
+    assert torch.equal(out[0]["flat2"], out[1]["flat2"])
+
+
+@pytest.mark.parametrize("overlap", ["1"])
+def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical(overlap):
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, overlap), nprocs=world, join=True)
     # single-rank per-task gradients of the two shards, same replica, no exchange, no update
     singles = []
     for r in range(world):
