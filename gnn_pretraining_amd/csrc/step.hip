@@ -16,8 +16,8 @@ namespace {
     } while (0)
 
 constexpr int H = 256;
-constexpr int NEV = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 4;
-constexpr int EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;   // NEV - 1: running statistics (aux)
+constexpr int NEV = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 5;
+constexpr int EV_LAYER0_DONE = NEV - 4, EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;   // NEV - 1: running statistics (aux)
 
 hipEvent_t* events() {   // one process drives one engine: a small static pool of timing-free events
     static hipEvent_t ev[NEV];
@@ -328,7 +328,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
     (void)hipStreamWaitEvent(main, ev[2], 0);
     if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved statistics
-    (void)hipEventRecord(ev[EV_HEADS_DONE], main);               // every head's parameter gradients are final (gmp_step_wait_grads)
+    if (d.dp_exchange) (void)hipEventRecord(ev[EV_HEADS_DONE], main);   // every head's parameter gradients are final (gmp_step_wait_grads)
     if (timing) (void)hipEventRecord(phase_events()[2 + GMP_STEP_LAYERS], main);
 
     // ---- stacked backbone backward: per-task parameter gradients from ONE pass.
@@ -373,6 +373,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
+        if (l == 0 && d.dp_exchange) (void)hipEventRecord(ev[EV_LAYER0_DONE], main);   // layers >= 1: the first record of layer l-1 serves
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
     }
     float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
@@ -394,29 +395,30 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
                                 d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
     }
-    (void)hipEventRecord(ev[EV_BWD_DONE], main);
+    if (d.dp_exchange) (void)hipEventRecord(ev[EV_BWD_DONE], main);
     if (timing) (void)hipEventRecord(phase_events()[GMP_STEP_PHASES], main);
     return GMP_OK;
 }
 
 // Data-parallel exchange beside the backward: `st` waits until the per-task gradients of one part of the model are final in
 // task_grads -- part 0: the task heads (written before the stacked backward starts), part 1 + k: backbone layer L-1-k (its
-// weight-gradient GEMMs and BatchNorm parameter sums on aux, its eps sum on main), last part: layer 0, the mask token and the
-// encoders (end of the backward).  Uses the events of the most recent gmp_pretrain_step_fwd_bwd of this process.
+// weight-gradient GEMMs and BatchNorm parameter sums on aux, its eps sum on main), last part: the mask token and the encoders
+// (end of the backward).  Uses the events of the most recent gmp_pretrain_step_fwd_bwd of this process (dp_exchange set).
 extern "C" int gmp_step_wait_grads(int part, gmp_stream_t st_) {
-    if (part < 0 || part > GMP_STEP_LAYERS) return gmp::fail(GMP_ERR_ARG, "step_wait_grads: part %d not in [0, %d]", part, GMP_STEP_LAYERS);
+    if (part < 0 || part > GMP_STEP_LAYERS + 1) return gmp::fail(GMP_ERR_ARG, "step_wait_grads: part %d not in [0, %d]", part, GMP_STEP_LAYERS + 1);
     hipStream_t st = (hipStream_t)st_;
     hipEvent_t* ev = events();
     hipEvent_t* evl = ev + 4 + GMP_STEP_MAX_TASKS;
     hipError_t e = hipSuccess;
     if (part == 0) {
         e = hipStreamWaitEvent(st, ev[EV_HEADS_DONE], 0);
-    } else if (part == GMP_STEP_LAYERS) {
-        e = hipStreamWaitEvent(st, ev[EV_BWD_DONE], 0);          // main joined aux's layer-0 / layer-1 GEMMs before the encoder backward
+    } else if (part == GMP_STEP_LAYERS + 1) {
+        e = hipStreamWaitEvent(st, ev[EV_BWD_DONE], 0);
     } else {
-        const int l = GMP_STEP_LAYERS - part;                    // 4 .. 1
+        const int l = GMP_STEP_LAYERS - part;                    // 4 .. 0
         e = hipStreamWaitEvent(st, evl[4 * l + 3], 0);           // aux: dW2, dW1 and both BatchNorm parameter sums of layer l
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, evl[4 * (l - 1)], 0);   // main: past layer l's eps sum (first record of layer l-1)
+        if (e == hipSuccess)                                     // main: past layer l's eps sum
+            e = hipStreamWaitEvent(st, l > 0 ? evl[4 * (l - 1)] : ev[EV_LAYER0_DONE], 0);
     }
     return e == hipSuccess ? GMP_OK : gmp::fail(GMP_ERR_LAUNCH, "step_wait_grads: hipStreamWaitEvent failed");
 }

@@ -106,6 +106,10 @@ class PackedGradSync:
         self.n, self.total = len(offs), pre[-1]
         self.table = torch.tensor(offs + pre, dtype=torch.int64, device=base.device)
         self.packed = torch.empty(self.total, dtype=torch.float32, device=base.device)
+        self.share = 1.0           # this message's share of the step's whole exchange (OverlappedGradSync sets it per part)
+        # diagnostic (scripts/diag_dp_overlap.py): stand in for the collective's run time on a box with one GPU by a spin kernel
+        # of GMP_DP_FAKE_US microseconds for the whole exchange, split over the parts by size
+        self._fake_us = float(os.environ.get("GMP_DP_FAKE_US", "0"))
 
     def average_(self) -> None:
         w = world_size()
@@ -116,6 +120,8 @@ class PackedGradSync:
         L.check(L.lib().gmp_segments_pack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total, st),
                 "gmp_segments_pack")
         dist.all_reduce(self.packed, op=dist.ReduceOp.SUM)
+        if self._fake_us > 0:
+            L.check(L.lib().gmp_spin_us(int(round(self._fake_us * self.share)), st), "gmp_spin_us")
         L.check(L.lib().gmp_segments_unpack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total,
                                             1.0 / w, st), "gmp_segments_unpack")
 
@@ -123,11 +129,11 @@ class PackedGradSync:
 class OverlappedGradSync:
     """The exchange of the stacked engine run BESIDE the stacked backward (libgnnmp
     gmp_step_wait_grads).  The per-task gradient matrix is cut into parts in the order the step finishes them -- the task
-    heads (final before the backward starts), then backbone layers 4 ... 1, then layer 0 + mask token + encoders -- and
+    heads (final before the backward starts), then backbone layers 4 ... 0, then mask token + encoders -- and
     every part is packed, all-reduced and written back on `comm` (one of the engine's two head streams, idle during the
     backward: the runtime has four hardware queues and the step already uses four streams, so no new stream is created)
-    as soon as the events of that part have fired.  Only the last part (about 6 of 36 MB for s4) is exposed after the
-    backward; RCCL runs a synchronous collective on the caller's current stream, so every collective is ordered behind
+    as soon as the events of that part have fired.  Only the last part (0.4 of 36 MB for s4) and the tail of layer 0's are exposed after
+    the backward; RCCL runs a synchronous collective on the caller's current stream, so every collective is ordered behind
     its own pack kernel and before its unpack kernel without host involvement.  The result is bitwise the one-message
     exchange: the same elementwise sums, only sent in pieces."""
 
@@ -135,6 +141,8 @@ class OverlappedGradSync:
         self.parts = [PackedGradSync(base, slices) for slices in parts]
         self.comm = comm
         self.total = sum(p.total for p in self.parts)
+        for p in self.parts:
+            p.share = p.total / max(self.total, 1)
 
     def average_(self, lib, main: "torch.cuda.Stream") -> None:
         if not _exchange_needed():

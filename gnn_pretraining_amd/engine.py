@@ -1191,14 +1191,13 @@ class StepEngine:
         if self.native and os.environ.get("GMP_DP_OVERLAP", "1") != "0":
             if self._packed_sync is None:
                 from .dist import OverlappedGradSync
-                # shared tensors by the part of the backward that finishes them: layer l >= 1 -> part L - l, the rest -> part L
-                ranges: List[List[List[int]]] = [[] for _ in range(GNN_NUM_LAYERS + 1)]
+                # shared tensors by the part of the backward that finishes them: layer l -> part L - l, the rest -> part L + 1
+                ranges: List[List[List[int]]] = [[] for _ in range(GNN_NUM_LAYERS + 2)]
                 shared = [n for n in self.names if self.off[n] < self.P_shared]
                 for i, n in enumerate(shared):
-                    part = GNN_NUM_LAYERS
+                    part = GNN_NUM_LAYERS + 1
                     if n.startswith("gnn_backbone.layers."):
-                        l = int(n.split(".")[2])
-                        part = GNN_NUM_LAYERS - l if l >= 1 else GNN_NUM_LAYERS
+                        part = GNN_NUM_LAYERS - int(n.split(".")[2])
                     end = self.off[shared[i + 1]] if i + 1 < len(shared) else self.P_shared
                     r = ranges[part]
                     if r and r[-1][1] == self.off[n]:
@@ -1206,7 +1205,7 @@ class StepEngine:
                     else:
                         r.append([self.off[n], end])
                 parts = [head_slices] + [[(t * self.P + lo, hi - lo) for t in range(self.T) for lo, hi in ranges[b]]
-                                         for b in range(1, GNN_NUM_LAYERS + 1)]
+                                         for b in range(1, GNN_NUM_LAYERS + 2)]
                 self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
             self._packed_sync.average_(self.lib, torch.cuda.current_stream(self.device))
             return
@@ -1331,6 +1330,7 @@ class StepEngine:
         d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
+        d.dp_exchange = int(self.grad_sync is not None)
         d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
         d.seg_ptr, d.seg_dom, d.src_row, d.tiles = p.d32["seg_ptr"], p.d32["seg_dom"], p.d32["src_row"], p.d32["tiles"]
         d.edge_index, d.rowmask = p.d64["edge_index"], p.d64.get("rowmask")

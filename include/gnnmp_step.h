@@ -82,6 +82,7 @@ typedef struct {
     int32_t N, E, S, max_seg, num_tiles, num_tasks, num_domains, dpad, training, hidden;
     int32_t max_seg_edges;        /* largest number of edges of one segment (the batch is block diagonal: CSR is built per segment) */
     float dropout_p;
+    int32_t dp_exchange;          /* nonzero: record the events gmp_step_wait_grads needs (data-parallel run) */
     uint64_t seed;
     /* uploaded index arrays */
     const int32_t *seg_ptr, *seg_dom, *src_row, *tiles;

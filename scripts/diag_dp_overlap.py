@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 if len(sys.argv) == 1:
     res = {}
-    for mode in ("none", "flat", "overlap"):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True)
+    # the last two: a 400 us spin kernel stands in for the collective (split over the parts by size): how much of it the backward hides
+    for mode, fake in (("none", "0"), ("flat", "0"), ("overlap", "0"), ("flat", "400"), ("overlap", "400")):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True, env=dict(os.environ, GMP_DP_FAKE_US=fake))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        res[mode] = json.loads(line[-1]) if line else r.stderr[-400:]
-        print(mode, res[mode], flush=True)
+        res[mode + "+" + fake] = json.loads(line[-1]) if line else r.stderr[-400:]
+        print(mode, "fake collective", fake, "us:", res[mode + "+" + fake], flush=True)
     sys.exit(0)
 
 mode = sys.argv[1]
