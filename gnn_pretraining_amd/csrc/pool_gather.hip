@@ -49,21 +49,40 @@ __global__ __launch_bounds__(BLOCK) void row_gather_scalar_kernel(const float* _
     }
 }
 
+// One workgroup per segment: its four waves take rows s + w, s + w + 4, ... and keep four row loads in flight each (a wave per
+// segment walking its ~30 rows one dependent load at a time was latency-bound: 12 us forward, 33 us backward for 64 graphs).
+// max is order-independent, so the result is bit-identical to the sequential sweep.
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
 __global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __restrict__ x, const int* __restrict__ ptr,
                                                             float4* __restrict__ out, int64_t B, int F4) {
-    const int lane = threadIdx.x % GMP_WAVE;
-    for (int64_t b = wave_id(); b < B; b += wave_count()) {
+    __shared__ float4 sh[WPB][GMP_WAVE];
+    const int lane = threadIdx.x % GMP_WAVE, w = threadIdx.x / GMP_WAVE;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         const int s = ptr[b], e = ptr[b + 1];
-        for (int c = lane; c < F4; c += GMP_WAVE) {
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> 0 (PyG new_zeros, include_self=False)
-            if (e > s) {
-                m = x[(int64_t)s * F4 + c];
-                for (int r = s + 1; r < e; ++r) {
-                    float4 v = x[(int64_t)r * F4 + c];
-                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        for (int c0 = 0; c0 < F4; c0 += GMP_WAVE) {
+            const int c = c0 + lane;
+            const float ninf = -__builtin_huge_valf();
+            float4 m = make_float4(ninf, ninf, ninf, ninf);
+            if (c < F4) {
+                int r = s + w;
+                for (; r + 3 * WPB < e; r += 4 * WPB) {
+                    const float4 v0 = x[(int64_t)r * F4 + c], v1 = x[(int64_t)(r + WPB) * F4 + c], v2 = x[(int64_t)(r + 2 * WPB) * F4 + c],
+                                 v3 = x[(int64_t)(r + 3 * WPB) * F4 + c];
+                    m = max4(max4(m, v0), max4(max4(v1, v2), v3));
                 }
+                for (; r < e; r += WPB) m = max4(m, x[(int64_t)r * F4 + c]);
             }
-            out[b * F4 + c] = m;
+            sh[w][lane] = m;
+            __syncthreads();
+            if (w == 0 && c < F4) {
+                m = max4(max4(sh[0][lane], sh[1][lane]), max4(sh[2][lane], sh[3][lane]));
+                if (e <= s) m = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> 0 (PyG new_zeros, include_self=False)
+                out[b * F4 + c] = m;
+            }
+            __syncthreads();
         }
     }
 }
@@ -73,29 +92,55 @@ __global__ __launch_bounds__(BLOCK) void seg_max_fwd_kernel(const float4* __rest
 // include_self=False, and torch still counts that initial 0 as one more tie when the
 // segment maximum equals 0 (N_to_distribute = (self == result) + #ties).  After ReLU
 // whole columns are 0, so this matters: such a column gets g / (n + 1), not g / n.
+__device__ __forceinline__ float4 eq4(float4 v, float4 m) { return make_float4(v.x == m.x, v.y == m.y, v.z == m.z, v.w == m.w); }
+__device__ __forceinline__ float4 add4f(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 __global__ __launch_bounds__(BLOCK) void seg_max_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
                                                             const float4* __restrict__ mx, const int* __restrict__ ptr,
                                                             float4* __restrict__ gx, int64_t B, int F4, int accumulate) {
-    const int lane = threadIdx.x % GMP_WAVE;
-    for (int64_t b = wave_id(); b < B; b += wave_count()) {
+    __shared__ float4 sh[WPB][GMP_WAVE];
+    const int lane = threadIdx.x % GMP_WAVE, w = threadIdx.x / GMP_WAVE;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         const int s = ptr[b], e = ptr[b + 1];
-        for (int c = lane; c < F4; c += GMP_WAVE) {
-            const float4 m = mx[b * F4 + c], gg = g[b * F4 + c];
-            float4 n = make_float4(m.x == 0.f, m.y == 0.f, m.z == 0.f, m.w == 0.f);
-            for (int r = s; r < e; ++r) {
-                float4 v = x[(int64_t)r * F4 + c];
-                n.x += v.x == m.x; n.y += v.y == m.y; n.z += v.z == m.z; n.w += v.w == m.w;
-            }
-            const float4 q = make_float4(gg.x / n.x, gg.y / n.y, gg.z / n.z, gg.w / n.w);
-            for (int r = s; r < e; ++r) {
-                float4 v = x[(int64_t)r * F4 + c];
-                float4 o = make_float4(v.x == m.x ? q.x : 0.f, v.y == m.y ? q.y : 0.f, v.z == m.z ? q.z : 0.f, v.w == m.w ? q.w : 0.f);
-                if (accumulate) {
-                    const float4 p = gx[(int64_t)r * F4 + c];
-                    o = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+        for (int c0 = 0; c0 < F4; c0 += GMP_WAVE) {
+            const int c = c0 + lane;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), gg = m, n = m;    // tie counts are small integers: exact in any order
+            if (c < F4) {
+                m = mx[b * F4 + c];
+                gg = g[b * F4 + c];
+                int r = s + w;
+                for (; r + 3 * WPB < e; r += 4 * WPB) {
+                    const float4 v0 = x[(int64_t)r * F4 + c], v1 = x[(int64_t)(r + WPB) * F4 + c], v2 = x[(int64_t)(r + 2 * WPB) * F4 + c],
+                                 v3 = x[(int64_t)(r + 3 * WPB) * F4 + c];
+                    n = add4f(add4f(n, eq4(v0, m)), add4f(add4f(eq4(v1, m), eq4(v2, m)), eq4(v3, m)));
                 }
-                gx[(int64_t)r * F4 + c] = o;
+                for (; r < e; r += WPB) n = add4f(n, eq4(x[(int64_t)r * F4 + c], m));
             }
+            sh[w][lane] = n;
+            __syncthreads();
+            if (c < F4) {
+                n = add4f(add4f(sh[0][lane], sh[1][lane]), add4f(sh[2][lane], sh[3][lane]));
+                n = add4f(n, eq4(m, make_float4(0.f, 0.f, 0.f, 0.f)));     // the zero-initialised output counts as one more tie
+                const float4 q = make_float4(gg.x / n.x, gg.y / n.y, gg.z / n.z, gg.w / n.w);
+                for (int r = s + w; r < e; r += 4 * WPB) {
+                    float4 v[4], p[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i * WPB < e) {
+                            v[i] = x[(int64_t)(r + i * WPB) * F4 + c];
+                            if (accumulate) p[i] = gx[(int64_t)(r + i * WPB) * F4 + c];
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i * WPB < e) {
+                            float4 o = make_float4(v[i].x == m.x ? q.x : 0.f, v[i].y == m.y ? q.y : 0.f, v[i].z == m.z ? q.z : 0.f,
+                                                   v[i].w == m.w ? q.w : 0.f);
+                            if (accumulate) o = add4f(o, p[i]);
+                            gx[(int64_t)(r + i * WPB) * F4 + c] = o;
+                        }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -172,7 +217,7 @@ extern "C" int gmp_segment_max_fwd(const float* x, const int32_t* ptr, float* ou
     if (int rc = feat_ok("segment_max_fwd", feat)) return rc;
     if (B < 0 || (B > 0 && (!x || !ptr || !out))) return gmp::fail(GMP_ERR_ARG, "segment_max_fwd: bad argument");
     if (B == 0) return GMP_OK;
-    hipLaunchKernelGGL(seg_max_fwd_kernel, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)x, ptr,
+    hipLaunchKernelGGL(seg_max_fwd_kernel, dim3((unsigned)(B < 65536 ? B : 65536)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)x, ptr,
                        (float4*)out, B, feat / 4);
     return gmp::check_launch("seg_max_fwd_kernel");
 }
@@ -182,7 +227,7 @@ extern "C" int gmp_segment_max_bwd(const float* g_out, const float* x, const flo
     if (int rc = feat_ok("segment_max_bwd", feat)) return rc;
     if (B < 0 || (B > 0 && (!g_out || !x || !out || !ptr || !g_x))) return gmp::fail(GMP_ERR_ARG, "segment_max_bwd: bad argument");
     if (B == 0) return GMP_OK;
-    hipLaunchKernelGGL(seg_max_bwd_kernel, dim3(grid_for(B)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)g_out,
+    hipLaunchKernelGGL(seg_max_bwd_kernel, dim3((unsigned)(B < 65536 ? B : 65536)), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)g_out,
                        (const float4*)x, (const float4*)out, ptr, (float4*)g_x, B, feat / 4, accumulate);
     return gmp::check_launch("seg_max_bwd_kernel");
 }

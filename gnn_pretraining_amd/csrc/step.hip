@@ -16,8 +16,34 @@ namespace {
     } while (0)
 
 constexpr int H = 256;
-constexpr int NEV = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 5;
-constexpr int EV_LAYER0_DONE = NEV - 4, EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;   // NEV - 1: running statistics (aux)
+constexpr int NEV = 4 + 2 * GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 7;
+constexpr int EV_LAYER0_DONE = NEV - 4, EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;
+constexpr int EV_HEAD_PARAMS = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS;   // [task], [MAX_TASKS] = the heads of the main stream: weight-gradient GEMMs done
+constexpr int EV_MAIN_HEADS = EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS + 1;           // main: input halves of its own heads done
+// ev[NEV - 1]: running statistics done (aux)
+
+// Gate flags (d.sync_flags, int32[64], all compared against the step's epoch): the same dependencies as the events above, carried
+// by sleeping waves instead of barrier packets when the caller vouches that the streams sit on different hardware queues.
+// A parked barrier packet costs every RUNNING queue ~2 us per kernel boundary (streams.hip); with the host several steps ahead
+// two or three of the four queues were parked most of the time.
+enum {
+    F_START = 0,                       // main -> aux: the step's uploads are done
+    F_FWD = 1,                         // main -> head streams: stacked forward done
+    F_HEAD_IN = 2,                     // [task] head stream -> main: input-gradient half done
+    F_MAIN_HEADS = 10,                 // main -> helper: input halves of main's own heads done
+    F_BWD_MA = 11,                     // [2 * layer + k] main -> aux: gu (k = 0) / g_z1 (k = 1) of the layer ready
+    F_AUX_L = 21,                      // [layer] aux -> exchange stream: the layer's weight gradients are final (data-parallel runs)
+    F_HEAD_PARAMS = 26,                // [task], [MAX_TASKS] = main's heads: weight-gradient GEMMs done (data-parallel runs)
+    F_L0 = 35,                         // main -> exchange stream: past layer 0's eps sum
+    F_BWD_DONE = 36,                   // main -> exchange stream: backward done
+    F_ERR = 63                         // a gate timed out
+};
+struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
+    int32_t* flags = nullptr;
+    int epoch = 0;
+    uint64_t head_params_mask = 0;
+};
+SyncState g_sync;
 
 hipEvent_t* events() {   // one process drives one engine: a small static pool of timing-free events
     static hipEvent_t ev[NEV];
@@ -84,19 +110,28 @@ int mlp2_fwd(const gmp_step_desc& d, const gmp_task_desc& t, float** d1_out, gmp
     return GMP_OK;
 }
 
-int mlp2_bwd(const gmp_step_desc& d, const gmp_task_desc& t, float* d1, gmp_stream_t st) {
+// Backward of the two-layer head, in two halves: the input-gradient chain (what the stacked backward waits for) and the two
+// weight-gradient GEMMs (they only feed task_grads).  mlp2_bwd_params reads g_out, d1, g_hid (after the ReLU/dropout gate) and x,
+// none of which the input chain overwrites, so it may run after it.
+int mlp2_bwd_inputs(const gmp_step_desc& d, const gmp_task_desc& t, gmp_stream_t st) {
+    const gmp_mlp2& m = t.mlp;
+    const int G = d.num_domains;
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_out, d.flat, nullptr, m.g_hid, G, m.rows, m.off_w3, nullptr, nullptr, nullptr, nullptr, 0,
+                                 m.k_hid, m.k_out, m.k_out, m.k_hid, m.k_hid, 1.f, 0, 0, nullptr, 0, st));
+    GMP_TRY(gmp_relu_dropout_bwd(m.g_hid, m.y1, m.g_hid, (int64_t)m.rows[G] * m.k_hid, d.training ? d.dropout_p : 0.f, d.seed, m.site, st));
+    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_hid, d.flat, nullptr, m.g_in, G, m.rows, m.off_w0, nullptr, nullptr, nullptr, nullptr, 0,
+                                 m.k_in, m.k_hid, m.k_hid, m.k_in, m.k_in, 1.f, 0, 0, nullptr, 0, st));
+    return GMP_OK;
+}
+
+int mlp2_bwd_params(const gmp_step_desc& d, const gmp_task_desc& t, float* d1, gmp_stream_t st) {
     const gmp_mlp2& m = t.mlp;
     const int G = d.num_domains;
     float* tg = d.task_grads;
     GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_out, d1, nullptr, tg, G, m.rows, nullptr, nullptr, m.tg_w3, tg, m.tg_b3, m.k_out, m.k_hid, 0,
                                  m.k_out, m.k_hid, m.k_hid, 1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
-    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_out, d.flat, nullptr, m.g_hid, G, m.rows, m.off_w3, nullptr, nullptr, nullptr, nullptr, 0,
-                                 m.k_hid, m.k_out, m.k_out, m.k_hid, m.k_hid, 1.f, 0, 0, nullptr, 0, st));
-    GMP_TRY(gmp_relu_dropout_bwd(m.g_hid, m.y1, m.g_hid, (int64_t)m.rows[G] * m.k_hid, d.training ? d.dropout_p : 0.f, d.seed, m.site, st));
     GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_hid, m.x, nullptr, tg, G, m.rows, nullptr, nullptr, m.tg_w0, tg, m.tg_b0, m.k_hid, m.k_in, 0,
                                  m.k_hid, m.k_in, m.k_in, 1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
-    GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_NN, m.g_hid, d.flat, nullptr, m.g_in, G, m.rows, m.off_w0, nullptr, nullptr, nullptr, nullptr, 0,
-                                 m.k_in, m.k_hid, m.k_hid, m.k_in, m.k_in, 1.f, 0, 0, nullptr, 0, st));
     return GMP_OK;
 }
 
@@ -107,13 +142,15 @@ int nt_xent_domains(const gmp_step_desc& d, const gmp_task_desc& t, float* z, fl
                                t.ntx_ws_bytes[0], st);
 }
 
-int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
+// A task head in two halves.  task_head_inputs: forward, loss, and the gradient with respect to the backbone output (added into
+// gA) -- what the stacked backward waits for.  task_head_params: the head's own weight-gradient GEMMs, which only feed
+// task_grads: on a stream of its own they run beside the first layers of the stacked backward instead of in front of it.
+int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1_out) {
     const gmp_task_desc& t = d.task[ti];
     const gmp_mlp2& m = t.mlp;
     const int64_t N = d.N;
     float* hL = d.h[GMP_STEP_LAYERS];
     float* gH = d.gA;
-    float* tg = d.task_grads;
     float* d1 = nullptr;
     switch (t.kind) {
         case GMP_TASK_NFM: {
@@ -123,7 +160,8 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
             GMP_TRY(gmp_mse_sum_fwd(m.y2, t.nfm_target, M * H, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
             GMP_TRY(gmp_mse_sum_bwd(m.y2, t.nfm_target, t.g_scale, m.g_out, M * H, st));
-            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            GMP_TRY(mlp2_bwd_inputs(d, t, st));
+            *d1_out = d1;
             return gmp_row_fill(gH, t.idx, m.g_in, M, N, H, 0, st);
         }
         case GMP_TASK_LP: {
@@ -136,16 +174,9 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(rc);
             GMP_TRY(gemm(GMP_GEMM_NT, ld1, w3, b3, t.lp_y2, K, 1, H, H, H, 1, false, st));
             GMP_TRY(gmp_sigmoid_bce_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
-            const int32_t one[2] = {0, (int32_t)K};
-            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3};
-            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy2, ld1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, 1, H, 0, 1, H, H, 1.f, 0, 0,
-                                         t.gemm_ws, t.gemm_ws_bytes, st));
+            *d1_out = ld1;
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy2, w3, nullptr, t.lp_gy1, K, H, 1, 1, H, H, false, st));
             GMP_TRY(gmp_relu_dropout_bwd(t.lp_gy1, t.lp_y1, t.lp_gy1, K * H, d.training ? d.dropout_p : 0.f, d.seed, t.lp_site, st));
-            // dW0 with db0 riding along (column sums of the A tile already in LDS)
-            const int64_t cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
-            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
-                                         1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy1, w0, nullptr, t.lp_gfeat, K, 3 * H, H, H, 3 * H, 3 * H, false, st));
             GMP_TRY(gmp_lp_edge_features_bwd(t.lp_gfeat, hL, t.lp_edges, t.lp_ghs, t.lp_ghd, N, K, H, st));
             float* g_rows = gH + (int64_t)H * t.row0;
@@ -158,7 +189,8 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(gmp_row_gather(hL, t.idx, nullptr, m.x, M, N, H, st));
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
             GMP_TRY(nt_xent_domains(d, t, m.y2, m.g_out, st));
-            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            GMP_TRY(mlp2_bwd_inputs(d, t, st));
+            *d1_out = d1;
             return gmp_row_fill(gH, t.idx, m.g_in, M, N, H, 0, st);
         }
         case GMP_TASK_GC: {
@@ -174,7 +206,8 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
                 return gmp::fail(GMP_ERR_LAUNCH, "step: read-out concat copy failed");
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
             GMP_TRY(nt_xent_domains(d, t, m.y2, m.g_out, st));
-            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            GMP_TRY(mlp2_bwd_inputs(d, t, st));
+            *d1_out = d1;
             if (hipMemcpy2DAsync(t.g_mean, H * sizeof(float), m.g_in, 2 * H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
                                  (hipStream_t)st) != hipSuccess ||
                 hipMemcpy2DAsync(t.g_max, H * sizeof(float), m.g_in + H, 2 * H * sizeof(float), H * sizeof(float), B, hipMemcpyDeviceToDevice,
@@ -189,7 +222,8 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
             GMP_TRY(gmp_mse_sum_fwd(m.y2, t.labels, (int64_t)B * m.k_out, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
             GMP_TRY(gmp_mse_sum_bwd(m.y2, t.labels, t.g_scale, m.g_out, (int64_t)B * m.k_out, st));
-            GMP_TRY(mlp2_bwd(d, t, d1, st));
+            GMP_TRY(mlp2_bwd_inputs(d, t, st));
+            *d1_out = d1;
             return gmp_row_gather(m.g_in, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st);
         }
         case GMP_TASK_DA: {
@@ -206,17 +240,50 @@ int task_head(const gmp_step_desc& d, int ti, gmp_stream_t st) {
             GMP_TRY(gemm(GMP_GEMM_NT, dd1, w3, b3, m.y2, B, Cc, Hd, Hd, Hd, Cc, false, st));
             GMP_TRY(gmp_cross_entropy_sum_fwd(m.y2, t.da_labels, B, Cc, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
             GMP_TRY(gmp_cross_entropy_sum_bwd(m.y2, t.da_labels, B, Cc, t.g_scale, m.g_out, st));
-            const int32_t one[2] = {0, B};
-            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3}, cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
-            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_out, dd1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, Cc, Hd, 0, Cc, Hd, Hd, 1.f, 0, 0,
-                                         nullptr, 0, st));
+            *d1_out = dd1;
             GMP_TRY(gemm(GMP_GEMM_NN, m.g_out, w3, nullptr, m.g_hid, B, Hd, Cc, Cc, Hd, Hd, false, st));
             GMP_TRY(gmp_relu_dropout_bwd(m.g_hid, m.y1, m.g_hid, (int64_t)B * Hd, pdrop, d.seed, t.lp_site, st));
-            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_hid, m.x, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, Hd, H, 0, Hd, H, H, 1.f, 0, 0,
-                                         nullptr, 0, st));
             // gradient reversal: d/d pooled = -lambda * (g_hid W0)
             GMP_TRY(gmp_gemm_f32(GMP_GEMM_NN, m.g_hid, w0, nullptr, m.g_in, B, H, Hd, Hd, H, H, -t.da_lambda, 0, 0, nullptr, 0, st));
             return gmp_row_gather(m.g_in, t.pool_gid, t.pool_ptr, gH + (int64_t)H * t.pool_r0, t.pool_M, B, H, st);
+        }
+        default:
+            return gmp::fail(GMP_ERR_ARG, "step: unknown task kind %d", t.kind);
+    }
+}
+
+int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1) {
+    const gmp_task_desc& t = d.task[ti];
+    const gmp_mlp2& m = t.mlp;
+    float* tg = d.task_grads;
+    switch (t.kind) {
+        case GMP_TASK_NFM:
+        case GMP_TASK_NC:
+            if (t.num_idx == 0) return GMP_OK;
+            return mlp2_bwd_params(d, t, d1, st);
+        case GMP_TASK_GC:
+            if (t.pool_B == 0) return GMP_OK;
+            return mlp2_bwd_params(d, t, d1, st);
+        case GMP_TASK_GP:
+            return mlp2_bwd_params(d, t, d1, st);
+        case GMP_TASK_LP: {
+            const int64_t K = t.lp_K;
+            const int32_t one[2] = {0, (int32_t)K};
+            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3}, cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy2, d1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, 1, H, 0, 1, H, H, 1.f, 0, 0,
+                                         t.gemm_ws, t.gemm_ws_bytes, st));
+            // dW0 with db0 riding along (column sums of the A tile already in LDS)
+            return gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
+                                        1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st);
+        }
+        case GMP_TASK_DA: {
+            const int B = t.pool_B, Hd = t.da_hidden, Cc = t.da_classes;
+            const int32_t one[2] = {0, B};
+            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3}, cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_out, d1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, Cc, Hd, 0, Cc, Hd, Hd, 1.f, 0, 0,
+                                         nullptr, 0, st));
+            return gmp_gemm_f32_grouped(GMP_GEMM_TN, m.g_hid, m.x, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, Hd, H, 0, Hd, H, H, 1.f, 0, 0,
+                                        nullptr, 0, st);
         }
         default:
             return gmp::fail(GMP_ERR_ARG, "step: unknown task kind %d", t.kind);
@@ -241,9 +308,24 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
 
     const bool timing = phase_timing();
     if (timing) (void)hipEventRecord(phase_events()[0], main);
+    // cross-stream dependencies: gates when the caller passed flags (streams on different hardware queues), events otherwise
+    const bool gates = d.sync_flags != nullptr;
+    g_sync.flags = gates ? d.sync_flags : nullptr;
+    g_sync.epoch = d.epoch;
+    g_sync.head_params_mask = 0;
+    auto signal = [&](int flag, hipEvent_t e, hipStream_t s) -> int {
+        if (gates) return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
+        (void)hipEventRecord(e, s);
+        return GMP_OK;
+    };
+    auto await = [&](int flag, hipEvent_t e, hipStream_t s) -> int {
+        if (gates) return gmp_gate_wait(d.sync_flags, 1ull << flag, d.epoch, d.sync_flags + F_ERR, (gmp_stream_t)s);
+        (void)hipStreamWaitEvent(s, e, 0);
+        return GMP_OK;
+    };
     // ---- CSR builds beside the encoders (they only need the uploaded indices)
-    (void)hipEventRecord(ev[0], main);
-    (void)hipStreamWaitEvent(aux, ev[0], 0);
+    GMP_TRY(signal(F_START, ev[0], main));
+    GMP_TRY(await(F_START, ev[0], aux));
     if (d.max_seg <= 8192 && d.max_seg_edges <= 24576)      // block diagonal: one workgroup per (segment, orientation)
         GMP_TRY(gmp_csr_build_segmented(d.edge_index, N, d.E, d.seg_ptr, d.seg_eptr, d.S, d.max_seg, d.max_seg_edges, d.csr[0], d.csr[1], d.csr[2], d.csr[3],
                                         d.csr[4], d.csr[5], d.csr_status, aux_));
@@ -293,42 +375,64 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
 
     // ---- task heads, each on its own stream
     if (hipMemsetAsync(d.gA, 0, (size_t)N * H * sizeof(float), main) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step: memset");
-    (void)hipEventRecord(ev[3], main);
+    GMP_TRY(signal(F_FWD, ev[3], main));
     if (timing) (void)hipEventRecord(phase_events()[1 + GMP_STEP_LAYERS], main);
-    if (defer) {          // running statistics of the 11 BatchNorms: off the critical path, on aux while the heads start
-        (void)hipStreamWaitEvent(aux, ev[3], 0);
-        c = bn_cfg(d, true, false, 0);
-        constexpr int NB = 2 * GMP_STEP_LAYERS + 1;
-        const int32_t* sg[NB];
-        int32_t ch[NB];
-        float *rm[NB], *rv[NB];
-        const float *sm[NB], *sr[NB];
-        sg[0] = d.seg_dom; ch[0] = H; rm[0] = d.enc_rm; rv[0] = d.enc_rv; sm[0] = d.enc_mean; sr[0] = d.enc_rstd;
-        for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
-            const gmp_layer_desc& L = d.layer[l];
-            const int a = 1 + 2 * l, b = 2 + 2 * l;
-            sg[a] = nullptr; ch[a] = 2 * H; rm[a] = L.rm1; rv[a] = L.rv1; sm[a] = L.m1; sr[a] = L.s1;
-            sg[b] = nullptr; ch[b] = H; rm[b] = L.rm2; rv[b] = L.rv2; sm[b] = L.m2; sr[b] = L.s2;
-        }
-        GMP_TRY(gmp_bn_running_update_batch(NB, d.seg_ptr, d.S, sg, ch, rm, rv, sm, sr, &c, aux_));
-        (void)hipEventRecord(ev[NEV - 1], aux);
-    }
     // heads on other streams first (their chains are the long ones: they start while main is still being fed), the ones packed
-    // onto main last; main joins the other streams only after everything is enqueued
+    // onto main last; main joins the other streams only after everything is enqueued.  Every head comes in two halves: main
+    // waits for the input-gradient half only; the weight-gradient GEMMs (they only feed task_grads) follow on the head's own
+    // stream and run beside the first layers of the stacked backward.  The heads that live on main hand theirs to `helper`.
+    float* head_d1[GMP_STEP_MAX_TASKS] = {nullptr};
+    hipStream_t helper = main;
+    for (int ti = 0; ti < T; ++ti) {
+        hipStream_t ts = (hipStream_t)task_streams[ti];
+        if (ts != main && (helper == main || ts != aux)) helper = ts;     // prefer a stream the backward does not use
+    }
+    bool main_heads = false;
     for (int pass = 0; pass < 2; ++pass)
         for (int ti = 0; ti < T; ++ti) {
             hipStream_t ts = (hipStream_t)task_streams[ti];
             if ((ts == main) != (pass == 1)) continue;
-            if (ts != main) (void)hipStreamWaitEvent(ts, ev[3], 0);
+            if (ts != main) GMP_TRY(await(F_FWD, ev[3], ts));
             if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
-            GMP_TRY(task_head(d, ti, task_streams[ti]));
-            if (ts != main) (void)hipEventRecord(ev[4 + ti], ts);
+            GMP_TRY(task_head_inputs(d, ti, task_streams[ti], &head_d1[ti]));
+            if (ts != main) {
+                GMP_TRY(signal(F_HEAD_IN + ti, ev[4 + ti], ts));
+                GMP_TRY(task_head_params(d, ti, task_streams[ti], head_d1[ti]));
+                (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
+                if (gates && d.dp_exchange) {
+                    GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + ti, d.epoch, task_streams[ti]));
+                    g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + ti);
+                }
+            } else {
+                main_heads = true;
+            }
         }
-    for (int ti = 0; ti < T; ++ti)
-        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
+    if (main_heads) {
+        if (helper != main) {
+            GMP_TRY(signal(F_MAIN_HEADS, ev[EV_MAIN_HEADS], main));
+            GMP_TRY(await(F_MAIN_HEADS, ev[EV_MAIN_HEADS], helper));
+        }
+        for (int ti = 0; ti < T; ++ti)
+            if ((hipStream_t)task_streams[ti] == main) GMP_TRY(task_head_params(d, ti, (gmp_stream_t)helper, head_d1[ti]));
+        if (helper != main) {
+            (void)hipEventRecord(ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], helper);
+            if (gates && d.dp_exchange) {
+                GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + GMP_STEP_MAX_TASKS, d.epoch, (gmp_stream_t)helper));
+                g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + GMP_STEP_MAX_TASKS);
+            }
+        }
+    }
+    if (gates) {          // one sleeping wave on main for all the heads' flags
+        uint64_t mask = 0;
+        for (int ti = 0; ti < T; ++ti)
+            if ((hipStream_t)task_streams[ti] != main) mask |= 1ull << (F_HEAD_IN + ti);
+        GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, main_));
+    } else {
+        for (int ti = 0; ti < T; ++ti)
+            if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
+    }
     (void)hipStreamWaitEvent(main, ev[2], 0);
-    if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved statistics
-    if (d.dp_exchange) (void)hipEventRecord(ev[EV_HEADS_DONE], main);   // every head's parameter gradients are final (gmp_step_wait_grads)
+    if (d.dp_exchange && !gates) (void)hipEventRecord(ev[EV_HEADS_DONE], main);   // every head's input half is done (gmp_step_wait_grads adds the params events)
     if (timing) (void)hipEventRecord(phase_events()[2 + GMP_STEP_LAYERS], main);
 
     // ---- stacked backbone backward: per-task parameter gradients from ONE pass.
@@ -353,8 +457,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
                            tg, tg, d.task_seg, L.tg_g2, L.tg_be2, split_pg ? 0 : T, &c, slice(1 + 2 * l), slice_bytes, main_));
-        (void)hipEventRecord(e[0], main);
-        (void)hipStreamWaitEvent(aux, e[0], 0);
+        GMP_TRY(signal(F_BWD_MA + 2 * l, e[0], main));
+        GMP_TRY(await(F_BWD_MA + 2 * l, e[0], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
@@ -364,23 +468,47 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
                            L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
-        (void)hipEventRecord(e[2], main);
-        (void)hipStreamWaitEvent(aux, e[2], 0);
+        GMP_TRY(signal(F_BWD_MA + 2 * l + 1, e[2], main));
+        GMP_TRY(await(F_BWD_MA + 2 * l + 1, e[2], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
         (void)hipEventRecord(e[3], aux);
+        if (gates && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
-        if (l == 0 && d.dp_exchange) (void)hipEventRecord(ev[EV_LAYER0_DONE], main);   // layers >= 1: the first record of layer l-1 serves
+        if (l == 0 && d.dp_exchange) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // layers >= 1: the first record of layer l-1 serves
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
+    }
+    if (defer) {          // running statistics of the 11 BatchNorms (training never reads them): on aux behind its last weight-gradient GEMM,
+                          // beside the encoder backward and PCGrad (in front of the aux stream's head it delayed that head by 45 us)
+        c = bn_cfg(d, true, false, 0);
+        constexpr int NB = 2 * GMP_STEP_LAYERS + 1;
+        const int32_t* sg[NB];
+        int32_t ch[NB];
+        float *rm[NB], *rv[NB];
+        const float *sm[NB], *sr[NB];
+        sg[0] = d.seg_dom; ch[0] = H; rm[0] = d.enc_rm; rv[0] = d.enc_rv; sm[0] = d.enc_mean; sr[0] = d.enc_rstd;
+        for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
+            const gmp_layer_desc& L = d.layer[l];
+            const int a = 1 + 2 * l, b = 2 + 2 * l;
+            sg[a] = nullptr; ch[a] = 2 * H; rm[a] = L.rm1; rv[a] = L.rv1; sm[a] = L.m1; sr[a] = L.s1;
+            sg[b] = nullptr; ch[b] = H; rm[b] = L.rm2; rv[b] = L.rv2; sm[b] = L.m2; sr[b] = L.s2;
+        }
+        GMP_TRY(gmp_bn_running_update_batch(NB, d.seg_ptr, d.S, sg, ch, rm, rv, sm, sr, &c, aux_));
+        (void)hipEventRecord(ev[NEV - 1], aux);
     }
     float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
     for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
         (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
         (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
     }
+    // join the heads' weight-gradient GEMMs, which ran beside the backward (long done; the mask-token sum below reuses the
+    // NFM head's input buffer, which its dW0 GEMM reads)
+    for (int ti = 0; ti < T; ++ti)
+        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + ti], 0);
+    if (main_heads && helper != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], 0);
     // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
     if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {
         const gmp_task_desc& t = d.task[d.nfm_task];
@@ -395,7 +523,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
                                 d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
     }
-    if (d.dp_exchange) (void)hipEventRecord(ev[EV_BWD_DONE], main);
+    if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved batch statistics they read
+    if (d.dp_exchange) GMP_TRY(signal(F_BWD_DONE, ev[EV_BWD_DONE], main));
     if (timing) (void)hipEventRecord(phase_events()[GMP_STEP_PHASES], main);
     return GMP_OK;
 }
@@ -406,12 +535,23 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
 // (end of the backward).  Uses the events of the most recent gmp_pretrain_step_fwd_bwd of this process (dp_exchange set).
 extern "C" int gmp_step_wait_grads(int part, gmp_stream_t st_) {
     if (part < 0 || part > GMP_STEP_LAYERS + 1) return gmp::fail(GMP_ERR_ARG, "step_wait_grads: part %d not in [0, %d]", part, GMP_STEP_LAYERS + 1);
+    if (g_sync.flags) {       // the step ran with gates: one sleeping wave on `st` for the flags of this part
+        uint64_t mask;
+        if (part == 0) mask = g_sync.head_params_mask;
+        else if (part == GMP_STEP_LAYERS + 1) mask = 1ull << F_BWD_DONE;
+        else {
+            const int l = GMP_STEP_LAYERS - part;
+            mask = (1ull << (F_AUX_L + l)) | (1ull << (l > 0 ? F_BWD_MA + 2 * (l - 1) : F_L0));
+        }
+        return gmp_gate_wait(g_sync.flags, mask, g_sync.epoch, g_sync.flags + F_ERR, st_);
+    }
     hipStream_t st = (hipStream_t)st_;
     hipEvent_t* ev = events();
     hipEvent_t* evl = ev + 4 + GMP_STEP_MAX_TASKS;
     hipError_t e = hipSuccess;
-    if (part == 0) {
+    if (part == 0) {      // input halves joined on main + every head's weight-gradient GEMMs (events of absent tasks: never recorded = no wait)
         e = hipStreamWaitEvent(st, ev[EV_HEADS_DONE], 0);
+        for (int i = 0; i <= GMP_STEP_MAX_TASKS && e == hipSuccess; ++i) e = hipStreamWaitEvent(st, ev[EV_HEAD_PARAMS + i], 0);
     } else if (part == GMP_STEP_LAYERS + 1) {
         e = hipStreamWaitEvent(st, ev[EV_BWD_DONE], 0);
     } else {

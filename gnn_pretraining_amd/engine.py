@@ -278,8 +278,17 @@ class StepEngine:
         # (longest first onto the least-loaded stream; main and aux are idle while the heads run).
         # ... and which hardware queue a stream lands on is measured, not assumed (streams.py): a kernel trace showed two of the
         # four streams sharing the main stream's queue, their heads running behind main's instead of beside them.
-        from .streams import concurrent_streams
-        self.aux_stream, *extra = concurrent_streams(dev, 3)
+        from . import streams as ST
+        self.aux_stream, *extra = ST.concurrent_streams(dev, 3)
+        # Cross-stream dependencies inside the native step are carried by GATES (a sleeping wave on a flag word, csrc/streams.hip)
+        # instead of events when all four streams were measured on hardware queues of their own: a queue parked on an event wait
+        # costs every running queue ~2 us per kernel boundary, and with the host several steps ahead two or three queues were
+        # parked most of the time (scripts/diag_blocked_queues.py).  In one in-order queue a gate ahead of its opener would never
+        # open, hence the condition.  GMP_STEP_GATES=0 keeps the events (needed under tools that serialise kernels, e.g. --pmc).
+        self.sync_flags = torch.zeros(64, dtype=torch.int32, device=dev)
+        self._epoch = 0
+        self.use_gates = (ST.last_report.get("calibrated") and ST.last_report.get("own_queue") == 3
+                          and os.environ.get("GMP_STEP_GATES", "1") != "0" and os.environ.get("GMP_HEAD_LAYOUT") != "per_task")
         self.comm_stream = extra[1]        # data-parallel exchange beside the backward (the head streams are idle by then)
         bins = [[0.0, extra[0]], [0.0, extra[1]], [0.0, self.aux_stream], [0.0, None]]      # None = the main stream
         self.task_streams = [None] * self.T
@@ -1216,7 +1225,14 @@ class StepEngine:
         self._packed_sync.average_()
 
     # ---- reporting (the only host syncs, and only on request) ---------------------------------------
+    def check_gates(self) -> None:
+        """A gate that timed out let its stream run ahead of a dependency: results since then are not to be trusted."""
+        if self.use_gates and int(self.sync_flags[63].item()) != 0:
+            raise L.GnnmpError("engine: a cross-stream gate timed out (streams sharing a hardware queue, or a tool serialising "
+                               "kernels?) -- rerun with GMP_STEP_GATES=0")
+
     def losses(self) -> Dict[str, float]:
+        self.check_gates()
         sums = self.loss_sums[:self.T].tolist()
         return {t: sums[i] / max(self.last_plan.sizes[t], 1) for i, t in enumerate(self.tasks)}
 
@@ -1331,6 +1347,8 @@ class StepEngine:
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
         d.dp_exchange = int(self.grad_sync is not None)
+        self._epoch += 1
+        d.epoch, d.sync_flags = self._epoch, (self.sync_flags.data_ptr() if self.use_gates else None)
         d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
         d.seg_ptr, d.seg_dom, d.src_row, d.tiles = p.d32["seg_ptr"], p.d32["seg_dom"], p.d32["src_row"], p.d32["tiles"]
         d.edge_index, d.rowmask = p.d64["edge_index"], p.d64.get("rowmask")

@@ -347,6 +347,14 @@ int gmp_segments_unpack(float* base, const float* packed, const int64_t* table_d
  * ------------------------------------------------------------------------- */
 int gmp_streams_share_queue(gmp_stream_t a, gmp_stream_t b, int* share_host);
 int gmp_spin_us(int microseconds, gmp_stream_t stream);
+/* Device-side gates: cross-stream dependencies without barrier packets.  Measured (scripts/diag_blocked_queues.py): every
+ * hardware queue parked on a hipStreamWaitEvent adds ~2 us to every kernel boundary of the queues that are running; a gate --
+ * one wave sleeping on flag words -- costs them nothing.  gmp_gate_wait parks one wave on `stream` until flags[i] >= want for
+ * every bit i of mask (flags: device int32[64]); after about a second it gives up and ORs 1 into *err (may be NULL).
+ * gmp_gate_open stores `value` to *flag from a kernel on its stream (after everything enqueued there before).  ONLY between
+ * streams on different hardware queues (gmp_streams_share_queue): in one in-order queue a gate ahead of its opener never opens. */
+int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t stream);
+int gmp_gate_open(int32_t* flag, int value, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one

@@ -83,7 +83,12 @@ typedef struct {
     int32_t max_seg_edges;        /* largest number of edges of one segment (the batch is block diagonal: CSR is built per segment) */
     float dropout_p;
     int32_t dp_exchange;          /* nonzero: record the events gmp_step_wait_grads needs (data-parallel run) */
+    int32_t epoch;                /* with sync_flags: strictly increasing from call to call (>= 1) */
     uint64_t seed;
+    int32_t* sync_flags;          /* device int32[64], zeroed once by the caller, or NULL.  Non-NULL = the caller has MEASURED that main,
+                                     aux and the task streams sit on different hardware queues (gmp_streams_share_queue): cross-stream
+                                     dependencies are then carried by gates (gmp_gate_wait / gmp_gate_open) instead of events.
+                                     sync_flags[63] becomes nonzero if a gate ever timed out. */
     /* uploaded index arrays */
     const int32_t *seg_ptr, *seg_dom, *src_row, *tiles;
     const int32_t* seg_eptr;      /* [S+1] first edge of each segment in edge_index */

@@ -39,3 +39,14 @@ L.check(L.lib().gmp_step_phase_detail_ms(det), "detail")
 print("last step detail (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f" % (
     det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3))
 print(os.environ.get("GMP_HEAD_LAYOUT", "packed"), "forward %.3f heads %.3f backward %.3f ms | whole synchronous step %.3f ms" % (acc[0] / n, acc[1] / n, acc[2] / n, t_all / n))
+
+# the same detail for the last step of a PIPELINED run (host several steps ahead, as in bench.py): no idle GPU in front of the step
+from gnn_pretraining_amd.pretrain.control import TemperatureScheduler
+temp = TemperatureScheduler(462 * 50)
+for rep in range(3):
+    B.run_steps(eng, temp, pool, gen, 100, start=80 + 100 * rep)
+    torch.cuda.synchronize()
+    L.check(L.lib().gmp_step_phase_detail_ms(det), "detail")
+    print("pipelined, last step (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f | sum %.0f" % (
+        det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3,
+        sum(det[i] for i in range(13)) * 1e3))
