@@ -74,10 +74,12 @@ def make_pool(seed: int, device, dpad: int):
 def run_steps(engine, temperature, pool, gen, n, start=0):
     """The body of run_training (reference pretrain.py:113-155): draw artefacts, 5 task losses, per-task
     gradients, PCGrad, clip, AdamW, scheduler step -- one engine.step per optimisation step."""
-    for inp, prepared in StepPrefetcher(engine, (pool[(start + i) % len(pool)] for i in range(n)), gen):
+    pf = StepPrefetcher(engine, (pool[(start + i) % len(pool)] for i in range(n)), gen)
+    for inp, prepared in pf:
         engine.temperature = temperature()
         engine.step(inp, gen, prepared=prepared)
         temperature.step()
+    return pf
 
 
 def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iters: int = 20):
@@ -236,7 +238,7 @@ def main() -> None:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    run_steps(engine, temperature, pool, gen, a.steps, start=PRIME_STEPS + a.warmup)
+    pf = run_steps(engine, temperature, pool, gen, a.steps, start=PRIME_STEPS + a.warmup)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
@@ -248,7 +250,8 @@ def main() -> None:
 
     hm = engine.host_ms
     log(f"{a.steps} steps in {elapsed:.3f} s; last-step losses {engine.losses()}")
-    log("host ms/step: " + ", ".join(f"{k} {hm[k] / max(hm['steps'], 1):.2f}" for k in ("draw", "plan", "upload", "launch")))
+    log("host ms/step: " + ", ".join(f"{k} {hm[k] / max(hm['steps'], 1):.2f}" for k in ("draw", "plan", "upload", "launch")) +
+        f"; prefetch thread busy {pf.busy_s / max(a.steps, 1) * 1e3:.2f}, launcher waited for it {pf.wait_s / max(a.steps, 1) * 1e3:.2f}")
     roof = roof_gemm = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)
@@ -267,7 +270,9 @@ def main() -> None:
             "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
                        "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "setup_steps": PRIME_STEPS, "index_rng": a.rng,
-                       "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy"},
+                       "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy",
+                       "cross_stream_sync": "gates" if engine.use_gates else "events",
+                       "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
             "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
         }
         emit(line)

@@ -26,3 +26,10 @@ def host_cores(cap: int = 16) -> int:
 
 def limit_host_threads(n: int = 1) -> None:
     torch.set_num_threads(max(1, min(n, host_cores())))
+    # Two Python threads share a step: the launcher (upload + one long C call, which releases the GIL) and the prefetcher
+    # (draw + plan of the next step).  With CPython's default 5 ms switch interval the launcher, back from its C call, waits for
+    # the prefetcher to reach a blocking call before it gets the GIL again; GMP_SWITCH_INTERVAL_US sets the interval.
+    us = os.environ.get("GMP_SWITCH_INTERVAL_US")
+    if us:
+        import sys
+        sys.setswitchinterval(max(float(us), 1.0) * 1e-6)

@@ -36,6 +36,28 @@ __global__ __launch_bounds__(THREADS) void segments_kernel(float* __restrict__ b
     }
 }
 
+// Host -> device upload of a few small arrays by ONE kernel that reads the pinned host buffers directly (they are mapped into
+// the device's address space): a step's index arrays are ~0.3 MB in four pieces, and four hipMemcpyAsync calls on the compute
+// stream meant four hand-overs to the copy engine with the queue parked behind each (parked queues tax every running queue,
+// streams.hip).  16-byte granules, 64 workgroups: ~0.25 MB of PCIe reads in flight.
+constexpr int UP_MAX = 4;
+struct UploadArgs {
+    const uint4* src[UP_MAX];
+    uint4* dst[UP_MAX];
+    int64_t pre[UP_MAX + 1];     // exclusive prefix of the piece lengths, in 16-byte granules
+    int n;
+};
+__global__ __launch_bounds__(THREADS) void upload_kernel(const UploadArgs a) {
+    const int64_t total = a.pre[a.n];
+    for (int64_t q = (int64_t)blockIdx.x * THREADS + threadIdx.x; q < total; q += (int64_t)gridDim.x * THREADS) {
+        int s = 0;
+#pragma unroll
+        for (int i = 1; i < UP_MAX; ++i)
+            if (i < a.n && q >= a.pre[i]) s = i;
+        a.dst[s][q - a.pre[s]] = a.src[s][q - a.pre[s]];
+    }
+}
+
 int check(const char* who, const void* base, const void* packed, const int64_t* table, int n) {
     if (!base || !packed || !table || n < 1 || n > MAX_SEGS) return gmp::fail(GMP_ERR_ARG, "%s: bad argument (n=%d, max %d)", who, n, MAX_SEGS);
     return GMP_OK;
@@ -58,4 +80,29 @@ extern "C" int gmp_segments_unpack(float* base, const float* packed, const int64
     const int blocks = (int)std::min<int64_t>(2048, (total / 4 + THREADS - 1) / THREADS);
     hipLaunchKernelGGL(segments_kernel<false>, dim3(blocks), dim3(THREADS), 0, (hipStream_t)stream, base, (float*)packed, table_dev, n, scale);
     return gmp::check_launch("segments_unpack");
+}
+
+extern "C" int gmp_upload(int n, const void* const* src_pinned_host, void* const* dst, const int64_t* bytes, gmp_stream_t stream) {
+    if (n < 1 || n > UP_MAX || !src_pinned_host || !dst || !bytes) return gmp::fail(GMP_ERR_ARG, "upload: bad argument (n=%d, max %d)", n, UP_MAX);
+    UploadArgs a;
+    a.n = n;
+    a.pre[0] = 0;
+    for (int i = 0; i < UP_MAX; ++i) {
+        a.src[i] = nullptr;
+        a.dst[i] = nullptr;
+        if (i < n) {
+            if (bytes[i] < 0 || (bytes[i] % 16) || (bytes[i] && (!src_pinned_host[i] || !dst[i])) || ((uintptr_t)src_pinned_host[i] % 16) ||
+                ((uintptr_t)dst[i] % 16))
+                return gmp::fail(GMP_ERR_ARG, "upload: piece %d: %lld bytes / pointers must be multiples of 16", i, (long long)bytes[i]);
+            a.src[i] = (const uint4*)src_pinned_host[i];
+            a.dst[i] = (uint4*)dst[i];
+            a.pre[i + 1] = a.pre[i] + bytes[i] / 16;
+        } else {
+            a.pre[i + 1] = a.pre[i];
+        }
+    }
+    if (a.pre[n] == 0) return GMP_OK;
+    const int blocks = (int)std::min<int64_t>(64, (a.pre[n] + THREADS - 1) / THREADS);
+    hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)stream, a);
+    return gmp::check_launch("upload_kernel");
 }

@@ -339,6 +339,15 @@ int gmp_segments_unpack(float* base, const float* packed, const int64_t* table_d
                         gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Host -> device upload of up to 4 small arrays by one kernel (the per-step index arrays: the reference builds them on the
+ * CPU, masks / negatives / views at pretrain_model.py:72-80, tasks.py:107-111, augmentations.py:17-111, and moves them with
+ * .to(device)).  src_pinned_host[i]: PINNED host memory (hipHostMalloc / torch pin_memory: mapped into the device's address
+ * space), dst[i]: device memory, bytes[i]: multiples of 16, all pointers 16-byte aligned; the three arrays are host arrays.
+ * The caller keeps a source buffer untouched until the stream has passed the call.
+ * ------------------------------------------------------------------------- */
+int gmp_upload(int n, const void* const* src_pinned_host, void* const* dst, const int64_t* bytes, gmp_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Streams and hardware queues (no reference counterpart: the reference runs everything on one stream).  The runtime maps a
  * process's HIP streams onto a few hardware queues (4 by default) and packets of one queue run in order, so two streams on
  * the same queue never overlap.  gmp_streams_share_queue MEASURES it: a 400 us spin kernel on `a`, an empty kernel on `b`;
