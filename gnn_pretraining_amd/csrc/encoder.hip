@@ -78,7 +78,7 @@ struct EncBwdArgs {
     float* out;                 // per-task gradient buffer
     float* part;                // nullable: [groups][RSPLIT][256][DP+1] row-slice partials
 };
-constexpr int RSPLIT = 8;
+constexpr int RSPLIT = 16;
 
 // block (group, slice): dW[c][k] = sum_r gz[r][c] x[r][k], db[c] = sum_r gz[r][c] over every RSPLIT-th 32-row tile of the
 // group (all of them without a workspace); partials are summed in slice order by encoder_bwd_reduce_kernel
@@ -111,11 +111,18 @@ __global__ __launch_bounds__(H) void encoder_bwd_kernel(const EncBwdArgs a) {
                 xs[rr][k] = v;
             }
             __syncthreads();
-            for (int rr = 0; rr < r1 - r0; ++rr) {
-                const float gv = a.gz[(int64_t)(r0 + rr) * H + c];
-                accb += gv;
+            // eight gradient rows in flight at a time (one dependent load per row made this kernel the longest of the step's tail);
+            // rows past the tile's end contribute gv = 0 against zeroed xs rows: the sums are unchanged bit for bit
+            for (int rr0 = 0; rr0 < r1 - r0; rr0 += 8) {
+                float gv[8];
 #pragma unroll
-                for (int k = 0; k < DP; ++k) acc[k] = fmaf(gv, xs[rr][k], acc[k]);
+                for (int j = 0; j < 8; ++j) gv[j] = (r0 + rr0 + j < r1) ? a.gz[(int64_t)(r0 + rr0 + j) * H + c] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (r0 + rr0 + j < r1) accb += gv[j];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) acc[k] = fmaf(gv[j], xs[rr0 + j][k], acc[k]);
+                }
             }
         }
     }

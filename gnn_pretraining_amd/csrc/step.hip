@@ -478,8 +478,29 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
-        if (l == 0 && d.dp_exchange) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // layers >= 1: the first record of layer l-1 serves
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
+    }
+    float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
+    for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
+        (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
+        (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
+    }
+    // join the heads' weight-gradient GEMMs, which ran beside the backward (long done; the mask-token sum below reuses the
+    // NFM head's input buffer, which its dW0 GEMM reads)
+    for (int ti = 0; ti < T; ++ti)
+        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + ti], 0);
+    if (main_heads && helper != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], 0);
+    // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM).  Training: the mask-token sum (3 launches
+    // that only feed task_grads) goes to aux, in front of the running statistics, beside the encoder backward on main.
+    const bool nfm_tail = d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0;
+    const bool tail_on_aux = defer && aux != main;
+    if (d.dp_exchange || (tail_on_aux && nfm_tail)) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // main is past layer 0 (and the joins above)
+    gmp_stream_t tail_st = tail_on_aux ? aux_ : main_;
+    if (nfm_tail) {
+        const gmp_task_desc& t = d.task[d.nfm_task];
+        if (tail_on_aux) GMP_TRY(await(F_L0, ev[EV_LAYER0_DONE], aux));
+        GMP_TRY(gmp_row_gather(gcur, t.idx, nullptr, t.mlp.x, t.num_idx, N, H, tail_st));
+        GMP_TRY(gmp_colsum(t.mlp.x, tg + d.tg_mask_token, t.num_idx, H, H, 0, t.loss_ws, t.loss_ws_bytes, tail_st));
     }
     if (defer) {          // running statistics of the 11 BatchNorms (training never reads them): on aux behind its last weight-gradient GEMM,
                           // beside the encoder backward and PCGrad (in front of the aux stream's head it delayed that head by 45 us)
@@ -498,22 +519,6 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         }
         GMP_TRY(gmp_bn_running_update_batch(NB, d.seg_ptr, d.S, sg, ch, rm, rv, sm, sr, &c, aux_));
         (void)hipEventRecord(ev[NEV - 1], aux);
-    }
-    float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
-    for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
-        (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
-        (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
-    }
-    // join the heads' weight-gradient GEMMs, which ran beside the backward (long done; the mask-token sum below reuses the
-    // NFM head's input buffer, which its dW0 GEMM reads)
-    for (int ti = 0; ti < T; ++ti)
-        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + ti], 0);
-    if (main_heads && helper != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], 0);
-    // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM)
-    if (d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0) {
-        const gmp_task_desc& t = d.task[d.nfm_task];
-        GMP_TRY(gmp_row_gather(gcur, t.idx, nullptr, t.mlp.x, t.num_idx, N, H, main_));
-        GMP_TRY(gmp_colsum(t.mlp.x, tg + d.tg_mask_token, t.num_idx, H, H, 0, d.loss_ws, d.loss_ws_bytes, main_));
     }
     if (d.enc_groups > 0) {
         c = bn_cfg(d, true, true, 1);
