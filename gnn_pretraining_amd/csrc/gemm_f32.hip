@@ -140,7 +140,20 @@ struct GemmArgs {
     int gsplit;
     float* gpart;
     float* gasum_part;
+    // cross-stream signal carried by this launch (gmp::signal_on_next_gemm): the first block stores sig_value to *sig_flag as it
+    // starts -- stream order has then retired, and flushed, everything enqueued before the GEMM -- which saves the separate
+    // one-thread "open the gate" launch (5-6 us on a busy chip) between a producer and the GEMM that follows it anyway
+    int* sig_flag;
+    int sig_value;
 };
+
+thread_local int* t_sig_flag = nullptr;
+thread_local int t_sig_value = 0;
+inline void take_signal(GemmArgs& g) {
+    g.sig_flag = t_sig_flag;
+    g.sig_value = t_sig_value;
+    t_sig_flag = nullptr;
+}
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int BK, bool FAST>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
@@ -153,6 +166,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
 
     const int t = threadIdx.x, lane = t % 64, wv = t / 64;
     const int wm = wv / 2, wn = wv % 2, l31 = lane & 31, half = lane >> 5;
+    if (g.sig_flag && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_store(g.sig_flag, g.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int64_t m0 = (int64_t)blockIdx.y * BM;
     const int64_t n0 = (int64_t)blockIdx.x * BN;
 
@@ -362,6 +377,14 @@ void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st, bool fa
 
 }  // namespace
 
+namespace gmp {
+void signal_on_next_gemm(int32_t* flag, int value) {
+    t_sig_flag = (int*)flag;
+    t_sig_value = value;
+}
+bool signal_pending() { return t_sig_flag != nullptr; }
+}  // namespace gmp
+
 extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     (void)mode;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -389,6 +412,7 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{A, B, bias, C, M, N, K, lda, ldb, ldc, alpha, accumulate, relu, 1, nullptr,
                (lda % 4 == 0) && aligned16(A), (ldb % 4 == 0) && aligned16(B)};
+    take_signal(g);
     const size_t want = gmp_gemm_f32_workspace_bytes(mode, M, N, K);
     if (want && workspace && workspace_bytes >= want) {
         g.splitk = (int)(want / ((size_t)M * N * sizeof(float)));
@@ -435,6 +459,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     g.vecB = (ldb % 4 == 0) && aligned16(B);
     g.groups = groups;
     g.gsplit = 1;
+    take_signal(g);
     g.asum = mode == GMP_GEMM_TN ? a_colsum : nullptr;
     int64_t max_rows = 0;
     for (int i = 0; i <= groups; ++i) {

@@ -16,6 +16,12 @@ namespace gmp {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// The next gmp_gemm_f32 / gmp_gemm_f32_grouped launch made by this host thread stores `value` to *flag when its first workgroup
+// starts (a cross-stream gate opened by the GEMM that follows the producer anyway, instead of by a launch of its own).  A GEMM
+// call that returns without launching leaves the signal pending: the caller checks signal_pending() and opens the gate itself.
+void signal_on_next_gemm(int32_t* flag, int value);
+bool signal_pending();
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -310,6 +310,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     if (timing) (void)hipEventRecord(phase_events()[0], main);
     // cross-stream dependencies: gates when the caller passed flags (streams on different hardware queues), events otherwise
     const bool gates = d.sync_flags != nullptr;
+    gmp::signal_on_next_gemm(nullptr, 0);           // nothing left pending by an earlier call that failed half-way
     g_sync.flags = gates ? d.sync_flags : nullptr;
     g_sync.epoch = d.epoch;
     g_sync.head_params_mask = 0;
@@ -317,6 +318,17 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (gates) return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
         (void)hipEventRecord(e, s);
         return GMP_OK;
+    };
+    // signal carried by the NEXT GEMM launched from this thread (it must be on stream s and follow immediately in host order):
+    // saves the one-thread launch on a critical chain; signal_flush opens the gate itself if that GEMM turned out to be empty
+    auto signal_by_gemm = [&](int flag, hipEvent_t e, hipStream_t s) {
+        if (gates) gmp::signal_on_next_gemm(d.sync_flags + flag, d.epoch);
+        else (void)hipEventRecord(e, s);
+    };
+    auto signal_flush = [&](int flag, hipStream_t s) -> int {
+        if (!gates || !gmp::signal_pending()) return GMP_OK;
+        gmp::signal_on_next_gemm(nullptr, 0);
+        return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
     };
     auto await = [&](int flag, hipEvent_t e, hipStream_t s) -> int {
         if (gates) return gmp_gate_wait(d.sync_flags, 1ull << flag, d.epoch, d.sync_flags + F_ERR, (gmp_stream_t)s);
@@ -396,8 +408,9 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
             GMP_TRY(task_head_inputs(d, ti, task_streams[ti], &head_d1[ti]));
             if (ts != main) {
-                GMP_TRY(signal(F_HEAD_IN + ti, ev[4 + ti], ts));
+                signal_by_gemm(F_HEAD_IN + ti, ev[4 + ti], ts);          // the head's first weight-gradient GEMM opens main's gate
                 GMP_TRY(task_head_params(d, ti, task_streams[ti], head_d1[ti]));
+                GMP_TRY(signal_flush(F_HEAD_IN + ti, ts));
                 (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
                 if (gates && d.dp_exchange) {
                     GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + ti, d.epoch, task_streams[ti]));
@@ -457,25 +470,27 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
                            tg, tg, d.task_seg, L.tg_g2, L.tg_be2, split_pg ? 0 : T, &c, slice(1 + 2 * l), slice_bytes, main_));
-        GMP_TRY(signal(F_BWD_MA + 2 * l, e[0], main));
+        signal_by_gemm(F_BWD_MA + 2 * l, e[0], main);            // g_u ready: the input-gradient GEMM below tells aux as it starts
+        GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
+        GMP_TRY(signal_flush(F_BWD_MA + 2 * l, main));
         GMP_TRY(await(F_BWD_MA + 2 * l, e[0], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
         (void)hipEventRecord(e[1], aux);
-        GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
         if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
                            L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
-        GMP_TRY(signal(F_BWD_MA + 2 * l + 1, e[2], main));
+        signal_by_gemm(F_BWD_MA + 2 * l + 1, e[2], main);        // g_z1 ready
+        GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
+        GMP_TRY(signal_flush(F_BWD_MA + 2 * l + 1, main));
         GMP_TRY(await(F_BWD_MA + 2 * l + 1, e[2], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
         (void)hipEventRecord(e[3], aux);
         if (gates && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
-        GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
