@@ -230,6 +230,8 @@ def main() -> None:
     # Set-up, not measurement: 30 untimed steps load every kernel's code object, grow the lazily sized workspaces and bring the
     # clocks out of idle, so that a short run (--steps 5 --warmup 2) times the same steady state a long one does.  The W warm-up
     # steps and the K timed steps the caller asked for follow, unchanged.
+    if world > 1:
+        torch.distributed.barrier()                 # ranks start stepping together (imports / pool building differ by seconds)
     run_steps(engine, temperature, pool, gen, PRIME_STEPS)
     log(f"rank {rank}/{world}: model + {POOL} step inputs resident, {PRIME_STEPS} set-up steps done, warming up {a.warmup} steps")
     run_steps(engine, temperature, pool, gen, a.warmup, start=PRIME_STEPS)

@@ -22,16 +22,21 @@ __global__ void spin_kernel(uint64_t ticks) {
 // ahead, so two or three of the four queues are parked most of the time.  A gate is one wave that sleeps on flag words until
 // all of them have reached `want`; the stream behind it is held by an ordinary running kernel and nobody else pays
 // (10.83 vs 10.80 us per kernel with three gated streams).  ONLY for streams on different hardware queues: a gate in front of
-// its own opener in one in-order queue would wait for its time-out.  A gate that times out (about a second) sets *err.
+// its own opener in one in-order queue would wait for its time-out.  A gate that times out (two minutes) sets *err.
 constexpr int GATE_FLAGS = 64;
+constexpr unsigned long long GATE_TIMEOUT_TICKS = 120ull * 100000000ull;   // 120 s of the 100 MHz wall clock
 __global__ void gate_wait_kernel(const int* flags, unsigned long long mask, int want, int* err) {
     const int lane = threadIdx.x;
     const bool mine = (mask >> lane) & 1ull;
     bool ok = !mine;
-    for (int i = 0; i < (1 << 23); ++i) {
+    const unsigned long long t0 = wall_clock64();
+    // exit every wave reaches: all flags seen, or the wall clock (checked every 1,024 polls) says the opener is not coming --
+    // two minutes, because in a data-parallel run the stream that opens this gate may itself be waiting for a peer GPU
+    for (unsigned i = 1;; ++i) {
         if (!ok) ok = __hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want;
         if (__all(ok)) return;
         __builtin_amdgcn_s_sleep(8);
+        if ((i & 1023u) == 0 && wall_clock64() - t0 > GATE_TIMEOUT_TICKS) break;
     }
     if (!ok && err) atomicOr(err, 1);
 }

@@ -359,7 +359,7 @@ int gmp_spin_us(int microseconds, gmp_stream_t stream);
 /* Device-side gates: cross-stream dependencies without barrier packets.  Measured (scripts/diag_blocked_queues.py): every
  * hardware queue parked on a hipStreamWaitEvent adds ~2 us to every kernel boundary of the queues that are running; a gate --
  * one wave sleeping on flag words -- costs them nothing.  gmp_gate_wait parks one wave on `stream` until flags[i] >= want for
- * every bit i of mask (flags: device int32[64]); after about a second it gives up and ORs 1 into *err (may be NULL).
+ * every bit i of mask (flags: device int32[64]); after two minutes it gives up and ORs 1 into *err (may be NULL).
  * gmp_gate_open stores `value` to *flag from a kernel on its stream (after everything enqueued there before).  ONLY between
  * streams on different hardware queues (gmp_streams_share_queue): in one in-order queue a gate ahead of its opener never opens. */
 int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t stream);

@@ -36,3 +36,31 @@ def test_spin_kernel_waits_about_as_long_as_asked():
     torch.cuda.synchronize()
     assert 1.5 <= e0.elapsed_time(e1) <= 4.0
     assert L.lib().gmp_spin_us(-1, st.cuda_stream) != 0
+
+
+def test_gate_opens_across_streams_and_waits_for_every_flag_of_its_mask():
+    from gnn_pretraining_amd import _lib as L, streams as ST
+    dev = torch.device("cuda:0")
+    lib = L.lib()
+    main = torch.cuda.current_stream(dev)
+    others = ST.concurrent_streams(dev, 3)
+    if ST.last_report["own_queue"] < 2:
+        pytest.skip("fewer than two hardware queues beside the main stream's")
+    flags = torch.zeros(64, dtype=torch.int32, device=dev)
+    out = torch.zeros(4, device=dev)
+    a, b = others[0], others[1]
+    # b is gated on flags 3 and 5 (epoch 7); main opens 3 after a 2 ms spin, a opens 5 after a 4 ms spin
+    L.check(lib.gmp_gate_wait(flags.data_ptr(), (1 << 3) | (1 << 5), 7, flags.data_ptr() + 4 * 63, b.cuda_stream), "wait")
+    e_b = torch.cuda.Event(); e_b.record(b)
+    L.check(lib.gmp_spin_us(2000, main.cuda_stream), "spin")
+    L.check(lib.gmp_gate_open(flags.data_ptr() + 4 * 3, 7, main.cuda_stream), "open")
+    e_m = torch.cuda.Event(); e_m.record(main)
+    e_m.synchronize()
+    assert not e_b.query()                                   # one flag of two: still closed
+    L.check(lib.gmp_spin_us(2000, a.cuda_stream), "spin")
+    L.check(lib.gmp_gate_open(flags.data_ptr() + 4 * 5, 8, a.cuda_stream), "open")      # a later epoch opens it too (>=)
+    torch.cuda.synchronize()
+    assert e_b.query()
+    f = flags.cpu()
+    assert int(f[3]) == 7 and int(f[5]) == 8 and int(f[63]) == 0
+    assert lib.gmp_gate_wait(None, 1, 1, None, main.cuda_stream) != 0
