@@ -96,6 +96,7 @@ class PackedGradSync:
         from . import _lib as L
         self._L = L
         self.base = base
+        slices = list(slices)
         offs = [int(o) for o, _ in slices]
         lens = [int(n) for _, n in slices]
         if any(o % 4 or n % 4 for o, n in zip(offs, lens)):
@@ -111,12 +112,13 @@ class PackedGradSync:
         # of GMP_DP_FAKE_US microseconds for the whole exchange, split over the parts by size
         self._fake_us = float(os.environ.get("GMP_DP_FAKE_US", "0"))
 
-    def average_(self) -> None:
+    def average_(self, stream_handle: Optional[int] = None) -> None:
+        """stream_handle: the hipStream_t of torch's CURRENT stream when the caller already has it (saves the lookup)."""
         w = world_size()
         if not _exchange_needed() or self.total == 0:
             return
         L = self._L
-        st = torch.cuda.current_stream(self.base.device).cuda_stream
+        st = stream_handle if stream_handle is not None else torch.cuda.current_stream(self.base.device).cuda_stream
         L.check(L.lib().gmp_segments_pack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total, st),
                 "gmp_segments_pack")
         dist.all_reduce(self.packed, op=dist.ReduceOp.SUM)
@@ -138,9 +140,19 @@ class OverlappedGradSync:
     exchange: the same elementwise sums, only sent in pieces."""
 
     def __init__(self, base: Tensor, parts, comm: "torch.cuda.Stream") -> None:
-        self.parts = [PackedGradSync(base, slices) for slices in parts]
+        # Consecutive parts may travel together (one pack / collective / unpack, sent when the LAST of them is final): every
+        # collective costs the launcher thread ~40 us, and at 1.6 ms per step the host has little to spare.  Default: heads |
+        # layers 4+3 | layers 2+1 | layer 0 | mask token + encoders -- the two parts whose collectives would otherwise be exposed
+        # after the backward stay on their own.  GMP_DP_GROUPS="0|1|2|3|4|5|6" sends every part by itself.
+        spec = os.environ.get("GMP_DP_GROUPS", "0|1,2|3,4|5|6")
+        groups = [[int(x) for x in g.split(",")] for g in spec.split("|")]
+        if sorted(i for g in groups for i in g) != list(range(len(parts))) or any(g != sorted(g) for g in groups):
+            raise ValueError(f"GMP_DP_GROUPS={spec!r} must list the parts 0..{len(parts) - 1} once each, in order")
+        self.wait_part = [g[-1] for g in groups]                  # the last part of a group is the one to wait for
+        self.parts = [PackedGradSync(base, [sl for i in g for sl in parts[i]]) for g in groups]
         self.comm = comm
         self.total = sum(p.total for p in self.parts)
+        self.host_s, self.calls = 0.0, 0              # host time spent enqueueing the exchange (scripts/diag_dp_overlap.py)
         for p in self.parts:
             p.share = p.total / max(self.total, 1)
 
@@ -148,9 +160,13 @@ class OverlappedGradSync:
         if not _exchange_needed():
             return
         from . import _lib as L
+        import time as _t
+        t0 = _t.perf_counter()
         with torch.cuda.stream(self.comm):
             handle = self.comm.cuda_stream
-            for b, part in enumerate(self.parts):
+            for b, part in zip(self.wait_part, self.parts):
                 L.check(lib.gmp_step_wait_grads(b, handle), "gmp_step_wait_grads")
-                part.average_()
+                part.average_(handle)
         main.wait_stream(self.comm)
+        self.host_s += _t.perf_counter() - t0
+        self.calls += 1

@@ -672,6 +672,23 @@ class StepEngine:
                     rm[r0:r0 + len(m)] = m
             a64["rowmask"] = rm.view(np.int64)
         p.a32, p.a64 = a32, a64
+        # the upload image of the step, packed here (prefetch thread) so the launcher thread only makes two block copies into
+        # its pinned slot: every array starts 16-byte aligned
+        def pack(arrs, dtype, gran, cap, what):
+            lay, parts, o = {}, [], 0
+            for name, arr in arrs.items():
+                a = np.ascontiguousarray(np.asarray(arr).reshape(-1), dtype=dtype)
+                lay[name] = o
+                pad = (-a.size) % gran
+                parts.append(a)
+                if pad:
+                    parts.append(np.zeros(pad, dtype=dtype))
+                o += a.size + pad
+            if o > cap:
+                raise L.GnnmpError(f"engine: {what} staging buffer too small")
+            return (np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)), lay
+        p.cat32, p.lay32 = pack(a32, np.int32, 4, getattr(self, "i32_cap", 1 << 62), "int32")     # (no capacities on a host-only engine)
+        p.cat64, p.lay64 = pack(a64, np.int64, 2, getattr(self, "i64_cap", 1 << 62), "int64")
         return p
 
     # ------------------------------------------------------------------ device helpers
@@ -763,23 +780,9 @@ class StepEngine:
         if slot["event"] is not None:
             slot["event"].synchronize()                  # the copy that read this slot STAGES steps ago is done
         pin32, pin64, pinf = slot["pin32"], slot["pin64"], slot["pinf"]
-        n32, n64 = pin32.numpy(), pin64.numpy()
-        o32 = o64 = 0
-        lay32, lay64 = {}, {}
-        for name, arr in p.a32.items():
-            a = np.asarray(arr).reshape(-1)
-            if o32 + a.size > self.i32_cap:
-                raise L.GnnmpError("engine: int32 staging buffer too small")
-            n32[o32:o32 + a.size] = a
-            lay32[name] = o32
-            o32 += (a.size + 3) // 4 * 4
-        for name, arr in p.a64.items():
-            a = np.asarray(arr).reshape(-1)
-            if o64 + a.size > self.i64_cap:
-                raise L.GnnmpError("engine: int64 staging buffer too small")
-            n64[o64:o64 + a.size] = a
-            lay64[name] = o64
-            o64 += (a.size + 1) // 2 * 2
+        o32, o64, lay32, lay64 = p.cat32.size, p.cat64.size, p.lay32, p.lay64
+        pin32.numpy()[:o32] = p.cat32
+        pin64.numpy()[:o64] = p.cat64
         nf = pinf.numpy()
         nf[:64] = 0.0
         for ti, t in enumerate(self.tasks):

@@ -45,7 +45,9 @@ B.run_steps(eng, temp, pool, gen, 80 if NS >= 400 else 20)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 B.run_steps(eng, temp, pool, gen, NS, start=80)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"ms_per_step": round(dt / NS * 1e3, 3), "sync": type(eng._packed_sync).__name__,
+hm = eng.host_ms
+print(json.dumps({"ms_per_step": round(dt / NS * 1e3, 3), "host_launch_ms": round(hm["launch"] / hm["steps"], 3), "host_upload_ms": round(hm["upload"] / hm["steps"], 3),
+                  "host_exchange_ms": round(getattr(eng._packed_sync, "host_s", 0.0) / max(getattr(eng._packed_sync, "calls", 0), 1) * 1e3, 3), "sync": type(eng._packed_sync).__name__,
                   "message_MB": round(getattr(eng._packed_sync, "total", 0) * 4 / 1e6, 1), "streams": dict(ST.last_report)}))
 if mode != "none":
     dist.destroy_process_group()

@@ -70,7 +70,7 @@ def test_overlapped_exchange_sends_the_same_slices_and_gives_the_same_bits(flat_
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, out, "1"), nprocs=world, join=True)
     assert out[0]["kind"] == "OverlappedGradSync" and flat_exchange[0]["kind"] == "PackedGradSync"
-    assert len(out[0]["parts"]) == 7                                        # heads, layers 4..0, mask token + encoders
+    assert len(out[0]["parts"]) == 5                                        # heads | layers 4+3 | layers 2+1 | layer 0 | mask token + encoders
     cover = lambda parts: sorted((o, n) for part in parts for (o, n) in part)
     def merged(sl):                                                         # union of half-open float ranges
         res = []
