@@ -233,6 +233,8 @@ def main() -> None:
     if world > 1:
         torch.distributed.barrier()                 # ranks start stepping together (imports / pool building differ by seconds)
     run_steps(engine, temperature, pool, gen, PRIME_STEPS)
+    from gnn_pretraining_amd import streams as ST
+    log(f"streams: {ST.last_report}, cross-stream sync: {'gates' if engine.use_gates else 'events'}")
     log(f"rank {rank}/{world}: model + {POOL} step inputs resident, {PRIME_STEPS} set-up steps done, warming up {a.warmup} steps")
     run_steps(engine, temperature, pool, gen, a.warmup, start=PRIME_STEPS)
     log("timing")

@@ -36,6 +36,7 @@ enum {
     F_HEAD_PARAMS = 26,                // [task], [MAX_TASKS] = main's heads: weight-gradient GEMMs done (data-parallel runs)
     F_L0 = 35,                         // main -> exchange stream: past layer 0's eps sum
     F_BWD_DONE = 36,                   // main -> exchange stream: backward done
+    F_AUX_DONE = 37,                   // aux -> main: everything aux did for this step is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
@@ -412,7 +413,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
                 GMP_TRY(task_head_params(d, ti, task_streams[ti], head_d1[ti]));
                 GMP_TRY(signal_flush(F_HEAD_IN + ti, ts));
                 (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
-                if (gates && d.dp_exchange) {
+                if (gates) {
                     GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + ti, d.epoch, task_streams[ti]));
                     g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + ti);
                 }
@@ -429,7 +430,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             if ((hipStream_t)task_streams[ti] == main) GMP_TRY(task_head_params(d, ti, (gmp_stream_t)helper, head_d1[ti]));
         if (helper != main) {
             (void)hipEventRecord(ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], helper);
-            if (gates && d.dp_exchange) {
+            if (gates) {
                 GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + GMP_STEP_MAX_TASKS, d.epoch, (gmp_stream_t)helper));
                 g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + GMP_STEP_MAX_TASKS);
             }
@@ -444,7 +445,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         for (int ti = 0; ti < T; ++ti)
             if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[4 + ti], 0);
     }
-    (void)hipStreamWaitEvent(main, ev[2], 0);
+    if (!gates) (void)hipStreamWaitEvent(main, ev[2], 0);     // (with an LP head its join implies it; without one ev[1] does)
     if (d.dp_exchange && !gates) (void)hipEventRecord(ev[EV_HEADS_DONE], main);   // every head's input half is done (gmp_step_wait_grads adds the params events)
     if (timing) (void)hipEventRecord(phase_events()[2 + GMP_STEP_LAYERS], main);
 
@@ -460,13 +461,25 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     const bool split_pg = d.bn_ws_bytes >= bn_slice * (2 * GMP_STEP_LAYERS + 1);
     auto slice = [&](int i) { return (void*)((char*)d.bn_ws + (split_pg ? bn_slice * (size_t)i : 0)); };
     const size_t slice_bytes = split_pg ? bn_slice : d.bn_ws_bytes;
+    // Per-layer g_u / g_z1 buffers (gu_l / gz1_l): aux may lag main by any number of layers and main never waits for it inside
+    // the backward.  (A wait on an event that was not complete when it was ENQUEUED costs the waiting stream 3-4 us even when
+    // the event has long fired by the time the packet is reached -- scripts/diag_blocked_queues.py -- and the host runs ahead.)
+    // Without them: two alternating copies, guarded by event waits two layers later.
+    const bool per_layer = d.gu_l[0] != nullptr && d.gz1_l[0] != nullptr;
+    // main's encoder backward and aux's grouped weight-gradient GEMMs each get half of gemm_ws (no join between them)
+    const size_t ws_half = per_layer ? (d.gemm_ws_bytes / 2) & ~(size_t)255 : 0;
+    void* const aux_ws = d.gemm_ws;
+    const size_t aux_ws_bytes = per_layer ? ws_half : d.gemm_ws_bytes;
+    void* const enc_ws = per_layer ? (void*)((char*)d.gemm_ws + ws_half) : d.gemm_ws;
+    const size_t enc_ws_bytes = per_layer ? d.gemm_ws_bytes - ws_half : d.gemm_ws_bytes;
+    const bool lean = gates && per_layer;        // no event waits on main from here to the end of the call
     float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
-        float* gu = (l & 1) ? d.gB2 : d.gB;
-        float* gz1 = (l & 1) ? d.gW3 : d.gW2;
+        float* gu = per_layer ? d.gu_l[l] : ((l & 1) ? d.gB2 : d.gB);
+        float* gz1 = per_layer ? d.gz1_l[l] : ((l & 1) ? d.gW3 : d.gW2);
         hipEvent_t* e = evl + 4 * l;
-        if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 1], 0);   // dW2 of layer l+2 has read this gu copy
+        if (!per_layer && l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 1], 0);   // dW2 of layer l+2 has read this gu copy
         c = bn_cfg(d, true, true, 10 + l);
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
                            tg, tg, d.task_seg, L.tg_g2, L.tg_be2, split_pg ? 0 : T, &c, slice(1 + 2 * l), slice_bytes, main_));
@@ -476,9 +489,9 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(await(F_BWD_MA + 2 * l, e[0], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
-                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
+                                     1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
         (void)hipEventRecord(e[1], aux);
-        if (l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
+        if (!per_layer && l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
                            L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
@@ -488,32 +501,42 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(await(F_BWD_MA + 2 * l + 1, e[2], aux));
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
-                                     1.f, 0, 0, d.gemm_ws, d.gemm_ws_bytes, aux_));
+                                     1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
         (void)hipEventRecord(e[3], aux);
         if (gates && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
     }
-    float* gu = d.gB;     // scratch for the encoder backward below (layer 0 used gB; its dW2 GEMM is awaited first)
-    for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
-        (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
-        (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
+    float* gu = d.gB;     // scratch for the encoder backward below (without per-layer buffers layer 0 used gB: its dW2 GEMM is awaited first)
+    if (!lean) {
+        for (int l = 0; l < GMP_STEP_LAYERS && l < 2; ++l) {
+            (void)hipStreamWaitEvent(main, evl[4 * l + 1], 0);
+            (void)hipStreamWaitEvent(main, evl[4 * l + 3], 0);
+        }
+        // join the heads' weight-gradient GEMMs, which ran beside the backward (long done; the mask-token sum below reuses the
+        // NFM head's input buffer, which its dW0 GEMM reads)
+        for (int ti = 0; ti < T; ++ti)
+            if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + ti], 0);
+        if (main_heads && helper != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], 0);
     }
-    // join the heads' weight-gradient GEMMs, which ran beside the backward (long done; the mask-token sum below reuses the
-    // NFM head's input buffer, which its dW0 GEMM reads)
-    for (int ti = 0; ti < T; ++ti)
-        if ((hipStream_t)task_streams[ti] != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + ti], 0);
-    if (main_heads && helper != main) (void)hipStreamWaitEvent(main, ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], 0);
     // ---- below the backbone: mask token (NFM) and the encoders (every task but NFM).  Training: the mask-token sum (3 launches
     // that only feed task_grads) goes to aux, in front of the running statistics, beside the encoder backward on main.
     const bool nfm_tail = d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0;
     const bool tail_on_aux = defer && aux != main;
-    if (d.dp_exchange || (tail_on_aux && nfm_tail)) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // main is past layer 0 (and the joins above)
+    if (d.dp_exchange || (tail_on_aux && nfm_tail)) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // main is past layer 0
     gmp_stream_t tail_st = tail_on_aux ? aux_ : main_;
     if (nfm_tail) {
         const gmp_task_desc& t = d.task[d.nfm_task];
-        if (tail_on_aux) GMP_TRY(await(F_L0, ev[EV_LAYER0_DONE], aux));
+        if (lean) {           // one gate: main past layer 0, and the NFM head's dW0 GEMM (it reads the buffer reused below) done
+            const bool nfm_on_main = (hipStream_t)task_streams[d.nfm_task] == main;
+            uint64_t mask = 1ull << (F_HEAD_PARAMS + (nfm_on_main ? GMP_STEP_MAX_TASKS : d.nfm_task));
+            mask &= g_sync.head_params_mask;           // (heads of main with no helper stream ran inline: nothing to wait for)
+            if (tail_on_aux) mask |= 1ull << F_L0;
+            GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, tail_st));
+        } else if (tail_on_aux) {
+            GMP_TRY(await(F_L0, ev[EV_LAYER0_DONE], aux));
+        }
         GMP_TRY(gmp_row_gather(gcur, t.idx, nullptr, t.mlp.x, t.num_idx, N, H, tail_st));
         GMP_TRY(gmp_colsum(t.mlp.x, tg + d.tg_mask_token, t.num_idx, H, H, 0, t.loss_ws, t.loss_ws_bytes, tail_st));
     }
@@ -533,17 +556,26 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             sg[b] = nullptr; ch[b] = H; rm[b] = L.rm2; rv[b] = L.rv2; sm[b] = L.m2; sr[b] = L.s2;
         }
         GMP_TRY(gmp_bn_running_update_batch(NB, d.seg_ptr, d.S, sg, ch, rm, rv, sm, sr, &c, aux_));
-        (void)hipEventRecord(ev[NEV - 1], aux);
+        if (!lean) (void)hipEventRecord(ev[NEV - 1], aux);
     }
+    if (lean && aux != main) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_DONE, d.epoch, aux_));
     if (d.enc_groups > 0) {
         c = bn_cfg(d, true, true, 1);
+        // (its own slice of the BatchNorm scratch: aux may still be reducing layer 0's slices)
         GMP_TRY(gmp_bn_bwd(gcur, d.z0, nullptr, d.seg_ptr, d.seg_dom, d.S, d.max_seg, N, H, d.flat + d.enc_off_gamma0, d.flat + d.enc_off_beta0, d.enc_rm,
-                           d.enc_rv, d.enc_mean, d.enc_rstd, gu, tg, tg, d.enc_gseg, d.enc_tg_gamma, d.enc_tg_beta, d.enc_groups, &c, d.bn_ws,
-                           d.bn_ws_bytes, main_));
+                           d.enc_rv, d.enc_mean, d.enc_rstd, gu, tg, tg, d.enc_gseg, d.enc_tg_gamma, d.enc_tg_beta, d.enc_groups, &c,
+                           lean ? slice(0) : d.bn_ws, lean ? slice_bytes : d.bn_ws_bytes, main_));
         GMP_TRY(gmp_encoder_bwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, gu, d.num_domains, d.enc_d_in,
-                                d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, d.gemm_ws, d.gemm_ws_bytes, main_));
+                                d.dpad, d.enc_groups, d.enc_gseg, d.enc_tg_w, d.enc_tg_b, tg, enc_ws, enc_ws_bytes, main_));
     }
-    if (defer) (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved batch statistics they read
+    if (lean) {           // ONE sleeping wave joins everything that ran beside main: aux (weight gradients, mask token, running
+                          // statistics) and the heads' weight-gradient GEMMs -- instead of ten event waits at 3-4 us each
+        uint64_t mask = g_sync.head_params_mask;
+        if (aux != main) mask |= 1ull << F_AUX_DONE;
+        GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, main_));
+    } else if (defer) {
+        (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved batch statistics they read
+    }
     if (d.dp_exchange) GMP_TRY(signal(F_BWD_DONE, ev[EV_BWD_DONE], main));
     if (timing) (void)hipEventRecord(phase_events()[GMP_STEP_PHASES], main);
     return GMP_OK;

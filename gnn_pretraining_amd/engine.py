@@ -269,6 +269,8 @@ class StepEngine:
         self.gW = f(R, 2 * H)                                # [R,512] gradients
         self.gW2 = f(R, 2 * H)
         self.gB2, self.gW3 = f(R, H), f(R, 2 * H)
+        # per-layer g_u / g_z1 of the native executor's backward: aux never holds main back (gnnmp_step.h)
+        self.gu_l, self.gz1_l = [f(R, H) for _ in range(Lr)], [f(R, 2 * H) for _ in range(Lr)]
         self.rowdot = f(R)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs
         # the task heads are independent of each other: each has its own scratch and they share four streams
@@ -1290,6 +1292,8 @@ class StepEngine:
             Ld.m1, Ld.s1, Ld.m2, Ld.s2 = ptr(self.stat["m1"][l]), ptr(self.stat["s1"][l]), ptr(self.stat["m2"][l]), ptr(self.stat["s2"][l])
         d.gA, d.gB, d.gW, d.gW2, d.rowdot = ptr(self.gA), ptr(self.gB), ptr(self.gW), ptr(self.gW2), ptr(self.rowdot)
         d.gB2, d.gW3 = ptr(self.gB2), ptr(self.gW3)
+        for l in range(GNN_NUM_LAYERS):
+            d.gu_l[l], d.gz1_l[l] = ptr(self.gu_l[l]), ptr(self.gz1_l[l])
         d.bn_ws, d.bn_ws_bytes = ptr(self.bn_ws), self.bn_ws.numel()
         d.gemm_ws, d.gemm_ws_bytes = ptr(self.gemm_ws), self.gemm_ws.numel()
         d.loss_ws, d.loss_ws_bytes = ptr(self.task_loss_ws[0]), self.task_loss_ws[0].numel()

@@ -45,3 +45,36 @@ for how in ("event", "gate"):
     for K in (0, 1, 2, 3):
         r = [run(K, how) for _ in range(3)]
         print(f"{how:6s} {K} parked streams: {min(r):6.2f} us per 10-us kernel of the chain (3 runs: {[round(x, 2) for x in r]})")
+
+
+# What does a wait on an event that has LONG completed cost the waiting stream?  The same chain with one / three such waits in
+# front of every kernel (events recorded on another stream and completed before the chain starts).
+def run_waits(nwait, late=False):
+    torch.cuda.synchronize()
+    done = []
+    if late:      # the events complete AFTER the host has enqueued the waits (20 ms spin) but before the chain runs (30 ms spin)
+        L.check(lib.gmp_spin_us(20000, others[0].cuda_stream), "spin")
+    for _ in range(3):
+        e = torch.cuda.Event()
+        L.check(lib.gmp_spin_us(1, others[0].cuda_stream), "spin")
+        e.record(others[0])
+        done.append(e)
+    if not late:
+        torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.check(lib.gmp_spin_us(30000, main.cuda_stream), "spin")
+    t0.record(main)
+    for _ in range(N):
+        for e in done[:nwait]:
+            main.wait_event(e)
+        L.check(lib.gmp_spin_us(US, main.cuda_stream), "spin")
+    t1.record(main)
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / N * 1e3
+
+
+for late in (False, True):
+    for nwait in (0, 1, 3):
+        r = [run_waits(nwait, late) for _ in range(3)]
+        print(f"{nwait} waits before every kernel on events complete {'when the chain RUNS (not yet when enqueued)' if late else 'when ENQUEUED'}: "
+              f"{min(r):6.2f} us per 10-us kernel (3 runs: {[round(x, 2) for x in r]})")
