@@ -311,6 +311,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     if (timing) (void)hipEventRecord(phase_events()[0], main);
     // cross-stream dependencies: gates when the caller passed flags (streams on different hardware queues), events otherwise
     const bool gates = d.sync_flags != nullptr;
+    const bool per_layer = d.gu_l[0] != nullptr && d.gz1_l[0] != nullptr;     // per-layer g_u / g_z1 buffers (see the backward below)
+    const bool lean = gates && per_layer;        // no event waits on main after the forward, no records nobody waits for
     gmp::signal_on_next_gemm(nullptr, 0);           // nothing left pending by an earlier call that failed half-way
     g_sync.flags = gates ? d.sync_flags : nullptr;
     g_sync.epoch = d.epoch;
@@ -412,7 +414,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
                 signal_by_gemm(F_HEAD_IN + ti, ev[4 + ti], ts);          // the head's first weight-gradient GEMM opens main's gate
                 GMP_TRY(task_head_params(d, ti, task_streams[ti], head_d1[ti]));
                 GMP_TRY(signal_flush(F_HEAD_IN + ti, ts));
-                (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
+                if (!lean) (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
                 if (gates) {
                     GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + ti, d.epoch, task_streams[ti]));
                     g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + ti);
@@ -429,7 +431,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         for (int ti = 0; ti < T; ++ti)
             if ((hipStream_t)task_streams[ti] == main) GMP_TRY(task_head_params(d, ti, (gmp_stream_t)helper, head_d1[ti]));
         if (helper != main) {
-            (void)hipEventRecord(ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], helper);
+            if (!lean) (void)hipEventRecord(ev[EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS], helper);
             if (gates) {
                 GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + GMP_STEP_MAX_TASKS, d.epoch, (gmp_stream_t)helper));
                 g_sync.head_params_mask |= 1ull << (F_HEAD_PARAMS + GMP_STEP_MAX_TASKS);
@@ -465,14 +467,12 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // the backward.  (A wait on an event that was not complete when it was ENQUEUED costs the waiting stream 3-4 us even when
     // the event has long fired by the time the packet is reached -- scripts/diag_blocked_queues.py -- and the host runs ahead.)
     // Without them: two alternating copies, guarded by event waits two layers later.
-    const bool per_layer = d.gu_l[0] != nullptr && d.gz1_l[0] != nullptr;
     // main's encoder backward and aux's grouped weight-gradient GEMMs each get half of gemm_ws (no join between them)
     const size_t ws_half = per_layer ? (d.gemm_ws_bytes / 2) & ~(size_t)255 : 0;
     void* const aux_ws = d.gemm_ws;
     const size_t aux_ws_bytes = per_layer ? ws_half : d.gemm_ws_bytes;
     void* const enc_ws = per_layer ? (void*)((char*)d.gemm_ws + ws_half) : d.gemm_ws;
     const size_t enc_ws_bytes = per_layer ? d.gemm_ws_bytes - ws_half : d.gemm_ws_bytes;
-    const bool lean = gates && per_layer;        // no event waits on main from here to the end of the call
     float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
@@ -490,7 +490,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
                                      1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
-        (void)hipEventRecord(e[1], aux);
+        if (!lean) (void)hipEventRecord(e[1], aux);      // (a record costs its stream ~3 us: only where somebody waits for it)
         if (!per_layer && l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
         GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
@@ -502,7 +502,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
-        (void)hipEventRecord(e[3], aux);
+        if (!lean) (void)hipEventRecord(e[3], aux);
         if (gates && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
         GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));

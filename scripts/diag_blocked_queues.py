@@ -78,3 +78,24 @@ for late in (False, True):
         r = [run_waits(nwait, late) for _ in range(3)]
         print(f"{nwait} waits before every kernel on events complete {'when the chain RUNS (not yet when enqueued)' if late else 'when ENQUEUED'}: "
               f"{min(r):6.2f} us per 10-us kernel (3 runs: {[round(x, 2) for x in r]})")
+
+
+# ... and what does an event RECORD between two kernels cost the recording stream?
+def run_records(nrec):
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.check(lib.gmp_spin_us(30000, main.cuda_stream), "spin")
+    t0.record(main)
+    evs = []
+    for _ in range(N):
+        for _ in range(nrec):
+            e = torch.cuda.Event(); e.record(main); evs.append(e)
+        L.check(lib.gmp_spin_us(US, main.cuda_stream), "spin")
+    t1.record(main)
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / N * 1e3
+
+
+for nrec in (0, 1, 2):
+    r = [run_records(nrec) for _ in range(3)]
+    print(f"{nrec} event records before every kernel: {min(r):6.2f} us per 10-us kernel (3 runs: {[round(x, 2) for x in r]})")
