@@ -159,7 +159,6 @@ int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1
             if (M == 0) return GMP_OK;
             GMP_TRY(gmp_row_gather(hL, t.idx, nullptr, m.x, M, N, H, st));
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
-            GMP_TRY(gmp_mse_sum_fwd(m.y2, t.nfm_target, M * H, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
             GMP_TRY(gmp_mse_sum_bwd(m.y2, t.nfm_target, t.g_scale, m.g_out, M * H, st));
             GMP_TRY(mlp2_bwd_inputs(d, t, st));
             *d1_out = d1;
@@ -221,7 +220,6 @@ int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1
             const int B = t.pool_B;
             GMP_TRY(gmp_segment_sum(hL, t.pool_ptr, nullptr, m.x, B, H, 1, 0, st));
             GMP_TRY(mlp2_fwd(d, t, &d1, st));
-            GMP_TRY(gmp_mse_sum_fwd(m.y2, t.labels, (int64_t)B * m.k_out, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st));
             GMP_TRY(gmp_mse_sum_bwd(m.y2, t.labels, t.g_scale, m.g_out, (int64_t)B * m.k_out, st));
             GMP_TRY(mlp2_bwd_inputs(d, t, st));
             *d1_out = d1;
@@ -258,7 +256,10 @@ int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1)
     const gmp_mlp2& m = t.mlp;
     float* tg = d.task_grads;
     switch (t.kind) {
-        case GMP_TASK_NFM:
+        case GMP_TASK_NFM:      // the loss VALUE (two launches, reporting only) is not on the chain the backward waits for
+            if (t.num_idx == 0) return GMP_OK;
+            GMP_TRY(mlp2_bwd_params(d, t, d1, st));
+            return gmp_mse_sum_fwd(m.y2, t.nfm_target, t.num_idx * H, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st);
         case GMP_TASK_NC:
             if (t.num_idx == 0) return GMP_OK;
             return mlp2_bwd_params(d, t, d1, st);
@@ -266,7 +267,8 @@ int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1)
             if (t.pool_B == 0) return GMP_OK;
             return mlp2_bwd_params(d, t, d1, st);
         case GMP_TASK_GP:
-            return mlp2_bwd_params(d, t, d1, st);
+            GMP_TRY(mlp2_bwd_params(d, t, d1, st));
+            return gmp_mse_sum_fwd(m.y2, t.labels, (int64_t)t.pool_B * m.k_out, t.loss_sum, t.loss_ws, t.loss_ws_bytes, st);
         case GMP_TASK_LP: {
             const int64_t K = t.lp_K;
             const int32_t one[2] = {0, (int32_t)K};

@@ -319,7 +319,7 @@ class StepEngine:
         # head workspaces (rows bounded by max_rows / edges)
         self.KMAX = self.max_edges
         self.hd = {k: f(n, c) for k, (n, c) in {
-            "nfm_in": (R, H), "nfm_y1": (R, H), "nfm_d1": (R, H), "nfm_y2": (R, H), "nfm_tgt": (R, H), "nfm_g": (R, H), "nfm_g1": (R, H),
+            "nfm_in": (R, H), "nfm_y1": (R, H), "nfm_d1": (R, H), "nfm_y2": (R, H), "nfm_tgt": (R, H), "nfm_g": (R, H), "nfm_g1": (R, H), "nfm_gin": (R, H),
             "lp_feat": (self.KMAX, 3 * H), "lp_y1": (self.KMAX, H), "lp_d1": (self.KMAX, H), "lp_gy1": (self.KMAX, H),
             "lp_gfeat": (self.KMAX, 3 * H), "lp_ghs": (self.KMAX, H), "lp_ghd": (self.KMAX, H),
             "nc_in": (2 * R, H), "nc_y1": (2 * R, H), "nc_d1": (2 * R, H), "nc_z": (2 * R, 128), "nc_gz": (2 * R, 128), "nc_g1": (2 * R, H), "nc_gin": (2 * R, H),
@@ -1298,7 +1298,7 @@ class StepEngine:
         d.gemm_ws, d.gemm_ws_bytes = ptr(self.gemm_ws), self.gemm_ws.numel()
         d.loss_ws, d.loss_ws_bytes = ptr(self.task_loss_ws[0]), self.task_loss_ws[0].numel()
         hd = self.hd
-        mlp_cfg = {"node_feat_mask": (H, H, H, "nfm_in", "nfm_y1", "nfm_d1", "nfm_y2", "nfm_g", "nfm_g1", "nfm_y2"),
+        mlp_cfg = {"node_feat_mask": (H, H, H, "nfm_in", "nfm_y1", "nfm_d1", "nfm_y2", "nfm_g", "nfm_g1", "nfm_gin"),   # (y2 is read again by the deferred loss sum)
                    "node_contrast": (H, H, 128, "nc_in", "nc_y1", "nc_d1", "nc_z", "nc_gz", "nc_g1", "nc_gin"),
                    "graph_contrast": (2 * H, H, 128, "gc_in", "gc_y1", "gc_d1", "gc_z", "gc_gz", "gc_g1", "gc_gin"),
                    "graph_prop": (H, 2 * H, GRAPH_PROPERTY_DIM, "gp_in", "gp_y1", "gp_d1", None, None, "gp_g1", "gp_gin")}
