@@ -37,6 +37,7 @@ enum {
     F_L0 = 35,                         // main -> exchange stream: past layer 0's eps sum
     F_BWD_DONE = 36,                   // main -> exchange stream: backward done
     F_AUX_DONE = 37,                   // aux -> main: everything aux did for this step is done
+    F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step

@@ -156,7 +156,9 @@ class OverlappedGradSync:
         for p in self.parts:
             p.share = p.total / max(self.total, 1)
 
-    def average_(self, lib, main: "torch.cuda.Stream") -> None:
+    def average_(self, lib, main: "torch.cuda.Stream", gate=None) -> None:
+        """gate: (flags data_ptr, epoch) of the engine when its streams sit on hardware queues of their own -- the main stream
+        then waits for the exchange through a gate (flag 38) instead of an event (record + wait: ~6 us on this hardware)."""
         if not _exchange_needed():
             return
         from . import _lib as L
@@ -167,6 +169,11 @@ class OverlappedGradSync:
             for b, part in zip(self.wait_part, self.parts):
                 L.check(lib.gmp_step_wait_grads(b, handle), "gmp_step_wait_grads")
                 part.average_(handle)
-        main.wait_stream(self.comm)
+        if gate is not None:
+            flags, epoch = gate
+            L.check(lib.gmp_gate_open(flags + 4 * 38, epoch, self.comm.cuda_stream), "gmp_gate_open")
+            L.check(lib.gmp_gate_wait(flags, 1 << 38, epoch, flags + 4 * 63, main.cuda_stream), "gmp_gate_wait")
+        else:
+            main.wait_stream(self.comm)
         self.host_s += _t.perf_counter() - t0
         self.calls += 1

@@ -1224,7 +1224,8 @@ class StepEngine:
                 parts = [head_slices] + [[(t * self.P + lo, hi - lo) for t in range(self.T) for lo, hi in ranges[b]]
                                          for b in range(1, GNN_NUM_LAYERS + 2)]
                 self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
-            self._packed_sync.average_(self.lib, torch.cuda.current_stream(self.device))
+            self._packed_sync.average_(self.lib, torch.cuda.current_stream(self.device),
+                                       gate=(self.sync_flags.data_ptr(), self._epoch) if self.use_gates else None)
             return
         if self._packed_sync is None:
             from .dist import PackedGradSync
