@@ -476,6 +476,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     const size_t aux_ws_bytes = per_layer ? ws_half : d.gemm_ws_bytes;
     void* const enc_ws = per_layer ? (void*)((char*)d.gemm_ws + ws_half) : d.gemm_ws;
     const size_t enc_ws_bytes = per_layer ? d.gemm_ws_bytes - ws_half : d.gemm_ws_bytes;
+    // Training with gates and per-layer buffers: the eps gradient of layer l (a 5 us sum over rowdot that only feeds task_grads)
+    // runs on aux at the start of aux's layer l-1 work -- the flag aux waits for there is set after main's aggregation backward
+    // of layer l -- from a rowdot buffer per layer; layer 0's goes to aux's tail.
+    const bool eps_on_aux = lean && defer && aux != main;
     float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
@@ -490,6 +494,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
         GMP_TRY(signal_flush(F_BWD_MA + 2 * l, main));
         GMP_TRY(await(F_BWD_MA + 2 * l, e[0], aux));
+        if (eps_on_aux && l + 1 < GMP_STEP_LAYERS) {
+            GMP_TRY(gmp_group_sum_1d(d.rowdot + (size_t)(l + 1) * N, T, d.task_row, d.layer[l + 1].tg_eps, tg, aux_));
+            if (d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l + 1, d.epoch, aux_));     // layer l+1 is final now
+        }
         if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(1 + 2 * l), d.S, H, tg, tg, d.task_seg, L.tg_g2, L.tg_be2, T, aux_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gu, L.r1, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w2, tg, L.tg_b2, H, 2 * H, 0, H, 2 * H, 2 * H,
                                      1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
@@ -506,9 +514,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
         if (!lean) (void)hipEventRecord(e[3], aux);
-        if (gates && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
-        GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, d.rowdot, N, H, main_));
-        GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, L.tg_eps, tg, main_));
+        if (gates && d.dp_exchange && !eps_on_aux) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
+        float* rowdot = eps_on_aux ? d.rowdot + (size_t)l * N : d.rowdot;
+        GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, rowdot, N, H, main_));
+        if (!eps_on_aux) GMP_TRY(gmp_group_sum_1d(rowdot, T, d.task_row, L.tg_eps, tg, main_));
         if (timing) (void)hipEventRecord(phase_events()[3 + GMP_STEP_LAYERS + (GMP_STEP_LAYERS - 1 - l)], main);
     }
     float* gu = d.gB;     // scratch for the encoder backward below (without per-layer buffers layer 0 used gB: its dW2 GEMM is awaited first)
@@ -527,19 +536,26 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // that only feed task_grads) goes to aux, in front of the running statistics, beside the encoder backward on main.
     const bool nfm_tail = d.nfm_task >= 0 && d.task[d.nfm_task].num_idx > 0;
     const bool tail_on_aux = defer && aux != main;
-    if (d.dp_exchange || (tail_on_aux && nfm_tail)) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // main is past layer 0
+    if (d.dp_exchange || (tail_on_aux && nfm_tail) || eps_on_aux) GMP_TRY(signal(F_L0, ev[EV_LAYER0_DONE], main));   // main is past layer 0
     gmp_stream_t tail_st = tail_on_aux ? aux_ : main_;
+    if (lean) {               // one gate in front of the tail work: main past layer 0 (when the work is on aux), and the NFM head's
+                              // dW0 GEMM done (it reads the buffer the mask-token sum reuses)
+        uint64_t mask = 0;
+        if (nfm_tail) {
+            const bool nfm_on_main = (hipStream_t)task_streams[d.nfm_task] == main;
+            mask = (1ull << (F_HEAD_PARAMS + (nfm_on_main ? GMP_STEP_MAX_TASKS : d.nfm_task))) & g_sync.head_params_mask;
+        }
+        if (tail_on_aux && (nfm_tail || eps_on_aux)) mask |= 1ull << F_L0;
+        GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, tail_st));
+    } else if (tail_on_aux && nfm_tail) {
+        GMP_TRY(await(F_L0, ev[EV_LAYER0_DONE], aux));
+    }
+    if (eps_on_aux) {
+        GMP_TRY(gmp_group_sum_1d(d.rowdot, T, d.task_row, d.layer[0].tg_eps, tg, aux_));
+        if (d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + 0, d.epoch, aux_));
+    }
     if (nfm_tail) {
         const gmp_task_desc& t = d.task[d.nfm_task];
-        if (lean) {           // one gate: main past layer 0, and the NFM head's dW0 GEMM (it reads the buffer reused below) done
-            const bool nfm_on_main = (hipStream_t)task_streams[d.nfm_task] == main;
-            uint64_t mask = 1ull << (F_HEAD_PARAMS + (nfm_on_main ? GMP_STEP_MAX_TASKS : d.nfm_task));
-            mask &= g_sync.head_params_mask;           // (heads of main with no helper stream ran inline: nothing to wait for)
-            if (tail_on_aux) mask |= 1ull << F_L0;
-            GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, tail_st));
-        } else if (tail_on_aux) {
-            GMP_TRY(await(F_L0, ev[EV_LAYER0_DONE], aux));
-        }
         GMP_TRY(gmp_row_gather(gcur, t.idx, nullptr, t.mlp.x, t.num_idx, N, H, tail_st));
         GMP_TRY(gmp_colsum(t.mlp.x, tg + d.tg_mask_token, t.num_idx, H, H, 0, t.loss_ws, t.loss_ws_bytes, tail_st));
     }

@@ -116,7 +116,8 @@ typedef struct {
     float *gB2, *gW3;             /* second copies of gB / gW2: weight-gradient GEMMs of layer l read them on the aux stream
                                      while layer l-1 already writes the other copy */
     float* gu_l[GMP_STEP_LAYERS];   /* [N,256] per layer, or all NULL: g_u of every backward layer in a buffer of its own ... */
-    float* gz1_l[GMP_STEP_LAYERS];  /* [N,512] per layer: ... and g_z1, so the aux stream may lag main by any number of layers */
+    float* gz1_l[GMP_STEP_LAYERS];  /* [N,512] per layer: ... and g_z1, so the aux stream may lag main by any number of layers.
+                                       With them `rowdot` must hold GMP_STEP_LAYERS * N floats (one slice per layer). */
     void* bn_ws; size_t bn_ws_bytes;
     void* gemm_ws; size_t gemm_ws_bytes;
     void* loss_ws; size_t loss_ws_bytes;
