@@ -447,13 +447,27 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
     return b + 256;
 }
 
-#define GMP_BN_SHORT_LAUNCH(KERNEL, MAXROWS, GRID, BLK, ST, ARGS)                      \
+// WIDE: 64 row lanes (512 threads) and half the rows per thread for the same (segment, 32 columns) tile.  The backward kernel
+// at 16 rows per thread needs 204 VGPRs: beside the resident blocks of the weight-gradient GEMM it runs next to in the step
+// (4 waves x 60 VGPRs per SIMD) only ONE such wave fits per SIMD, half the workgroups wait for a slot and the kernel takes
+// 31 us instead of the 15 us it takes alone; at 8 rows per thread two waves fit.  GMP_BN_WIDE=0/1 overrides (A/B aid).
+#define GMP_BN_SHORT_LAUNCH(KERNEL, MAXROWS, GRID, BLK, ST, ARGS, WIDE)                \
     do {                                                                               \
-        if ((MAXROWS) <= 4 * SRL) hipLaunchKernelGGL(KERNEL<4>, GRID, BLK, 0, ST, ARGS);      \
+        if (WIDE) {                                                                    \
+            const dim3 blk2(2 * SRL * SCQ);                                            \
+            if ((MAXROWS) <= 8 * SRL) hipLaunchKernelGGL((KERNEL<4, 2 * SRL>), GRID, blk2, 0, ST, ARGS);        \
+            else if ((MAXROWS) <= 16 * SRL) hipLaunchKernelGGL((KERNEL<8, 2 * SRL>), GRID, blk2, 0, ST, ARGS);  \
+            else hipLaunchKernelGGL((KERNEL<16, 2 * SRL>), GRID, blk2, 0, ST, ARGS);   \
+        } else if ((MAXROWS) <= 4 * SRL) hipLaunchKernelGGL(KERNEL<4>, GRID, BLK, 0, ST, ARGS);      \
         else if ((MAXROWS) <= 8 * SRL) hipLaunchKernelGGL(KERNEL<8>, GRID, BLK, 0, ST, ARGS); \
         else if ((MAXROWS) <= 16 * SRL) hipLaunchKernelGGL(KERNEL<16>, GRID, BLK, 0, ST, ARGS); \
         else hipLaunchKernelGGL((KERNEL<16, 2 * SRL>), GRID, dim3(2 * SRL * SCQ), 0, ST, ARGS);  \
     } while (0)
+
+static int bn_wide(int dflt) {
+    static const int forced = getenv("GMP_BN_WIDE") ? atoi(getenv("GMP_BN_WIDE")) : -1;
+    return forced >= 0 ? forced : dflt;
+}
 
 extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group, int S,
                           int64_t max_seg_rows, int64_t rows, int C, const float* gamma, const float* beta, float* running_mean,
@@ -474,7 +488,7 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a);
+        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(0) & 2) != 0);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         if (cfg->training) {
@@ -621,7 +635,7 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a);
+        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(1) & 1) != 0);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, blk, 0, st, a);
