@@ -126,7 +126,8 @@ typedef struct {
 
 size_t gmp_step_desc_size(void);
 /* main: stream of the stacked pass; task_streams[t]: one stream per task head (may all equal main);
- * aux: stream for the CSR builds (may equal main). */
+ * aux: stream for the CSR builds (may equal main).  NOT re-entrant: the call keeps its events, and what gmp_step_wait_grads
+ * needs, in process-wide state (one engine steps at a time in a process; engines may alternate between calls). */
 int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* desc, gmp_stream_t main, const gmp_stream_t* task_streams,
                               gmp_stream_t aux);
 /* Data-parallel exchange beside the backward: make `stream` wait until the per-task gradients of one part of

@@ -2,6 +2,8 @@
 the averaged per-task gradients equal the arithmetic mean of the two ranks' gradients, and the
 PCGrad result is then identical on both ranks (SURVEY.md section 8e oracle for DP)."""
 import os
+
+import pytest
 import random
 import socket
 
@@ -67,3 +69,23 @@ def test_dp_pcgrad_equals_mean_of_single_rank_gradients():
     for n in out[0]:                                    # replicas agree exactly
         if out[0][n] is not None:
             assert torch.equal(out[0][n], out[1][n])
+
+
+def test_overlapped_exchange_groups_parts_into_messages(monkeypatch):
+    """dist.OverlappedGradSync: which parts travel together (GMP_DP_GROUPS) and which part each message waits for."""
+    import torch
+    from gnn_pretraining_amd.dist import OverlappedGradSync
+    base = torch.zeros(7 * 64)
+    parts = [[(64 * i, 32), (64 * i + 32, 16)] for i in range(7)]          # two slices per part
+    monkeypatch.delenv("GMP_DP_GROUPS", raising=False)
+    s = OverlappedGradSync(base, parts, comm=None)
+    assert s.wait_part == [0, 2, 4, 5, 6] and [p.n for p in s.parts] == [2, 4, 4, 2, 2]
+    assert s.total == 7 * 48 and abs(sum(p.share for p in s.parts) - 1.0) < 1e-12
+    # a message's table: source offsets of its slices, then the exclusive prefix of their lengths
+    assert s.parts[1].table.tolist() == [64, 96, 128, 160, 0, 32, 48, 80, 96]
+    monkeypatch.setenv("GMP_DP_GROUPS", "0|1|2|3|4|5|6")
+    assert OverlappedGradSync(base, parts, comm=None).wait_part == list(range(7))
+    for bad in ("0|1|2|3|4|5", "0|2,1|3|4|5|6", "0|1|1|2|3|4|5|6"):
+        monkeypatch.setenv("GMP_DP_GROUPS", bad)
+        with pytest.raises(ValueError):
+            OverlappedGradSync(base, parts, comm=None)
