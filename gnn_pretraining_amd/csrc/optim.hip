@@ -24,6 +24,7 @@ struct MtArgs {
     const float* tg;           // [T][stride] per-task gradients
     int64_t stride;
     int T, K;
+    int k0, k1;                // the tensors this launch works on (gram / solve / combine); norm and AdamW always sweep all K
     const int64_t* off;        // [K]
     const int* len;            // [K]
     const unsigned char* has;  // [K][MAXT]
@@ -50,7 +51,7 @@ struct MtArgs {
 };
 
 __global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
-    const int k = blockIdx.x, j = blockIdx.y;
+    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
     const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
     if (j * per >= len) {                       // small tensors fill only their first chunks: the rest contribute zeros
         if (threadIdx.x < MAXT * MAXT) a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + threadIdx.x] = 0.0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
 
 // sum the chunk partials in chunk order into the symmetric Gram matrix of every tensor
 __global__ __launch_bounds__(64) void gram_finish_kernel(MtArgs a) {
-    const int k = blockIdx.x, x = threadIdx.x / MAXT, y = threadIdx.x % MAXT;
+    const int k = a.k0 + blockIdx.x, x = threadIdx.x / MAXT, y = threadIdx.x % MAXT;
     if (x >= a.T || y >= a.T || x > y) return;
     if (!a.has[k * MAXT + x] || !a.has[k * MAXT + y]) return;
     double s = 0.0;
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(64) void gram_finish_kernel(MtArgs a) {
 __global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
     __shared__ int s_conf[64], s_proj[64];
     int conf = 0, proj = 0;
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k < a.K) {
+    const int k = a.k0 + blockIdx.x * 64 + threadIdx.x;
+    if (k < a.k1) {
         const unsigned char* has = a.has + k * MAXT;
         const double* G = a.gram + (int64_t)k * MAXT * MAXT;
         int flag = 0;
@@ -221,17 +222,24 @@ __global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {            // per-block counts; summed (fixed order) by norm_kernel
-        a.block_metrics[2 * blockIdx.x] = s_conf[0];
-        a.block_metrics[2 * blockIdx.x + 1] = s_proj[0];
+    // per-block counts, summed by norm_kernel: a range [k0, k1) owns the slots k0 .. k1-1 (its blocks fill the first ones, the
+    // rest are zeroed), so ranges launched separately never share a slot and every slot is rewritten every step
+    if (threadIdx.x == 0) {
+        a.block_metrics[2 * (a.k0 + blockIdx.x)] = s_conf[0];
+        a.block_metrics[2 * (a.k0 + blockIdx.x) + 1] = s_proj[0];
     }
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + threadIdx.x; i < a.k1 - a.k0; i += 64) {
+            a.block_metrics[2 * (a.k0 + i)] = 0;
+            a.block_metrics[2 * (a.k0 + i) + 1] = 0;
+        }
 }
 
 // Every tensor starts on a 16-byte boundary of the flat buffers and is padded to a multiple of 4 floats (zeros in params, in the
 // gradients and in the optimizer state, and they stay zeros), so both sweeps below move float4.
 __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
     __shared__ float sh[TB / 64];
-    const int k = blockIdx.x, j = blockIdx.y;
+    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
     float ss = 0.f;
     if (a.flags[k]) {
         float w[MAXT];
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
     if (threadIdx.x == 0) {
         a.normsq[0] = (float)sh[0];
         int c = 0, pr = 0;
-        for (int b = 0; b < (a.K + 63) / 64; ++b) {
+        for (int b = 0; b < a.K; ++b) {
             c += a.block_metrics[2 * b];
             pr += a.block_metrics[2 * b + 1];
         }
@@ -324,17 +332,19 @@ __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
 extern "C" size_t gmp_mt_workspace_bytes(int num_tensors) {
     const size_t K = num_tensors > 0 ? num_tensors : 0;
     return K * MAXT * MAXT * sizeof(double) * (1 + GCH) + K * MAXT * sizeof(float) + K * sizeof(int) + K * CH * sizeof(float) +
-           (K / 64 + 2) * 2 * sizeof(int) + 1024;
+           (K + 2) * 2 * sizeof(int) + 1024;
 }
 
-extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
-                                        const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
-                                        const int32_t* order_host, int n_order, int last_task, int extra_task,
-                                        float* params, float* exp_avg, float* exp_avg_sq, float* steps,
-                                        const float* lr, const float* wd, float beta1, float beta2, float eps,
-                                        float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
-                                        int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
-                                        gmp_stream_t stream) {
+extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
+                                           const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
+                                           const int32_t* order_host, int n_order, int last_task, int extra_task,
+                                           float* params, float* exp_avg, float* exp_avg_sq, float* steps,
+                                           const float* lr, const float* wd, float beta1, float beta2, float eps,
+                                           float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
+                                           int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
+                                           int k_begin, int k_end, int phases, gmp_stream_t stream) {
+    if (k_begin < 0 || k_end > num_tensors || k_begin > k_end || !(phases & 3))
+        return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tensors [%d, %d) of %d, phases %d", k_begin, k_end, num_tensors, phases);
     if (num_tasks < 1 || num_tasks > MAXT || num_tensors < 1 || n_order < 1 || n_order > num_tasks)
         return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tasks=%d tensors=%d n_order=%d", num_tasks, num_tensors, n_order);
     if (!task_grads || !tensor_off || !tensor_len || !has || !order_host || !final_grad || !normsq_out || !metrics_out || !flags_out || !ws)
@@ -344,6 +354,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
     if (last_task >= num_tasks || extra_task >= num_tasks) return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: task index");
     MtArgs a{};
     a.tg = task_grads; a.stride = task_stride; a.T = num_tasks; a.K = num_tensors; a.off = tensor_off; a.len = tensor_len;
+    a.k0 = k_begin; a.k1 = k_end;
     a.has = has;
     char* w = (char*)ws;
     a.gram = (double*)w; w += (size_t)num_tensors * MAXT * MAXT * sizeof(double);
@@ -360,13 +371,31 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
     a.final_grad = final_grad; a.normsq = normsq_out; a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
     a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
     hipStream_t st = (hipStream_t)stream;
-    if (n_order > 1) {
-        hipLaunchKernelGGL(gram_kernel, dim3(num_tensors, GCH), dim3(TB), 0, st, a);
-        hipLaunchKernelGGL(gram_finish_kernel, dim3(num_tensors), dim3(64), 0, st, a);
+    const int nk = k_end - k_begin;
+    if ((phases & 1) && nk > 0) {
+        if (n_order > 1) {
+            hipLaunchKernelGGL(gram_kernel, dim3(nk, GCH), dim3(TB), 0, st, a);
+            hipLaunchKernelGGL(gram_finish_kernel, dim3(nk), dim3(64), 0, st, a);
+        }
+        hipLaunchKernelGGL(solve_kernel, dim3((nk + 63) / 64), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(combine_kernel, dim3(nk, CH), dim3(TB), 0, st, a);
     }
-    hipLaunchKernelGGL(solve_kernel, dim3((num_tensors + 63) / 64), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(combine_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
-    hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
-    if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
+    if (phases & 2) {
+        hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
+        if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
+    }
     return gmp::check_launch("mt_pcgrad_clip_adamw kernels");
+}
+
+extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
+                                        const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
+                                        const int32_t* order_host, int n_order, int last_task, int extra_task,
+                                        float* params, float* exp_avg, float* exp_avg_sq, float* steps,
+                                        const float* lr, const float* wd, float beta1, float beta2, float eps,
+                                        float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
+                                        int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
+                                        gmp_stream_t stream) {
+    return gmp_mt_pcgrad_clip_adamw_ex(task_grads, task_stride, num_tasks, num_tensors, tensor_off, tensor_len, has, order_host, n_order,
+                                       last_task, extra_task, params, exp_avg, exp_avg_sq, steps, lr, wd, beta1, beta2, eps, max_norm,
+                                       final_grad, normsq_out, metrics_out, flags_out, ws, ws_bytes, apply_update, 0, num_tensors, 3, stream);
 }

@@ -3,6 +3,8 @@
 // order: two "concurrent" streams that landed on the same queue serialise.  Which queue a stream gets depends on what else
 // the process created before, so the step executor does not guess: it MEASURES, once at start-up, which of its candidate
 // streams really run beside each other (gmp_streams_share_queue) and builds its four-stream layout from streams that do.
+#include <stdlib.h>
+
 #include "gnnmp_internal.h"
 
 namespace {
@@ -24,19 +26,19 @@ __global__ void spin_kernel(uint64_t ticks) {
 // (10.83 vs 10.80 us per kernel with three gated streams).  ONLY for streams on different hardware queues: a gate in front of
 // its own opener in one in-order queue would wait for its time-out.  A gate that times out (two minutes) sets *err.
 constexpr int GATE_FLAGS = 64;
-constexpr unsigned long long GATE_TIMEOUT_TICKS = 120ull * 100000000ull;   // 120 s of the 100 MHz wall clock
-__global__ void gate_wait_kernel(const int* flags, unsigned long long mask, int want, int* err) {
+__global__ void gate_wait_kernel(const int* flags, unsigned long long mask, int want, int* err, unsigned long long timeout_ticks) {
     const int lane = threadIdx.x;
     const bool mine = (mask >> lane) & 1ull;
     bool ok = !mine;
     const unsigned long long t0 = wall_clock64();
     // exit every wave reaches: all flags seen, or the wall clock (checked every 1,024 polls) says the opener is not coming --
-    // two minutes, because in a data-parallel run the stream that opens this gate may itself be waiting for a peer GPU
+    // two minutes by default (GMP_GATE_TIMEOUT_S; the tests use a few seconds), because in a data-parallel run the stream that
+    // opens this gate may itself be waiting for a peer GPU
     for (unsigned i = 1;; ++i) {
         if (!ok) ok = __hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want;
         if (__all(ok)) return;
         __builtin_amdgcn_s_sleep(8);
-        if ((i & 1023u) == 0 && wall_clock64() - t0 > GATE_TIMEOUT_TICKS) break;
+        if ((i & 1023u) == 0 && wall_clock64() - t0 > timeout_ticks) break;
     }
     if (!ok && err) atomicOr(err, 1);
 }
@@ -47,7 +49,8 @@ __global__ void gate_open_kernel(int* flag, int value) { __hip_atomic_store(flag
 extern "C" int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t st) {
     if (!flags) return gmp::fail(GMP_ERR_ARG, "gate_wait: null flags");
     if (!mask) return GMP_OK;
-    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(GATE_FLAGS), 0, (hipStream_t)st, (const int*)flags, (unsigned long long)mask, want, (int*)err);
+    static const unsigned long long ticks = (unsigned long long)(getenv("GMP_GATE_TIMEOUT_S") ? atof(getenv("GMP_GATE_TIMEOUT_S")) : 120.0) * 100000000ull;   // 100 MHz wall clock
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(GATE_FLAGS), 0, (hipStream_t)st, (const int*)flags, (unsigned long long)mask, want, (int*)err, ticks);
     return gmp::check_launch("gate_wait_kernel");
 }
 extern "C" int gmp_gate_open(int32_t* flag, int value, gmp_stream_t st) {

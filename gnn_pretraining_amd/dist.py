@@ -148,6 +148,7 @@ class OverlappedGradSync:
         groups = [[int(x) for x in g.split(",")] for g in spec.split("|")]
         if sorted(i for g in groups for i in g) != list(range(len(parts))) or any(g != sorted(g) for g in groups):
             raise ValueError(f"GMP_DP_GROUPS={spec!r} must list the parts 0..{len(parts) - 1} once each, in order")
+        self.groups = groups
         self.wait_part = [g[-1] for g in groups]                  # the last part of a group is the one to wait for
         self.parts = [PackedGradSync(base, [sl for i in g for sl in parts[i]]) for g in groups]
         self.comm = comm
@@ -156,19 +157,26 @@ class OverlappedGradSync:
         for p in self.parts:
             p.share = p.total / max(self.total, 1)
 
-    def average_(self, lib, main: "torch.cuda.Stream", gate=None) -> None:
+    def average_(self, lib, main: "torch.cuda.Stream", gate=None, exchange: bool = True, after_message=None) -> None:
         """gate: (flags data_ptr, epoch) of the engine when its streams sit on hardware queues of their own -- the main stream
-        then waits for the exchange through a gate (flag 38) instead of an event (record + wait: ~6 us on this hardware)."""
-        if not _exchange_needed():
+        then waits for the exchange through a gate (flag 38) instead of an event (record + wait: ~6 us on this hardware).
+        after_message(parts, stream_handle): called after every message's unpack with the parts it carried, to enqueue what
+        follows them on the exchange stream (the engine's per-part PCGrad).  exchange=False: no collectives (one rank), only the
+        waits and the callbacks."""
+        exchange = exchange and _exchange_needed()
+        if not exchange and after_message is None:
             return
         from . import _lib as L
         import time as _t
         t0 = _t.perf_counter()
         with torch.cuda.stream(self.comm):
             handle = self.comm.cuda_stream
-            for b, part in zip(self.wait_part, self.parts):
-                L.check(lib.gmp_step_wait_grads(b, handle), "gmp_step_wait_grads")
-                part.average_(handle)
+            for group, part in zip(self.groups, self.parts):
+                L.check(lib.gmp_step_wait_grads(group[-1], handle), "gmp_step_wait_grads")
+                if exchange:
+                    part.average_(handle)
+                if after_message is not None:
+                    after_message(group, handle)
         if gate is not None:
             flags, epoch = gate
             L.check(lib.gmp_gate_open(flags + 4 * 38, epoch, self.comm.cuda_stream), "gmp_gate_open")

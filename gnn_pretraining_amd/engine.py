@@ -175,6 +175,11 @@ class StepEngine:
         self._build_tables()
         self._alloc()
 
+    @property
+    def parts_beside_backward(self) -> bool:
+        """(self.native may be flipped after construction -- the tests do: only the native executor publishes the part flags)"""
+        return bool(self._parts_ok and self.native)
+
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self) -> None:
         m, dev = self.model, self.device
@@ -289,8 +294,12 @@ class StepEngine:
         # open, hence the condition.  GMP_STEP_GATES=0 keeps the events (needed under tools that serialise kernels, e.g. --pmc).
         self.sync_flags = torch.zeros(64, dtype=torch.int32, device=dev)
         self._epoch = 0
-        self.use_gates = (ST.last_report.get("calibrated") and ST.last_report.get("own_queue") == 3
-                          and os.environ.get("GMP_STEP_GATES", "1") != "0" and os.environ.get("GMP_HEAD_LAYOUT") != "per_task")
+        self.use_gates = bool(ST.last_report.get("calibrated") and ST.last_report.get("own_queue") == 3
+                              and os.environ.get("GMP_STEP_GATES", "1") != "0" and os.environ.get("GMP_HEAD_LAYOUT") != "per_task")
+        # PCGrad (and the data-parallel exchange) part by part beside the backward: needs the gates and the native executor
+        # (opt-in, GMP_OPT_OVERLAP=1: measured 1.58 against 1.54 ms/step on one GPU -- 28 small launches on the exchange stream beside
+        # the backward and a longer hand-over chain at the end cost more than the 58 us of Gram / solve / combine they take off it)
+        self._parts_ok = (self.use_gates and os.environ.get("GMP_DP_OVERLAP", "1") != "0" and os.environ.get("GMP_OPT_OVERLAP", "0") == "1")
         self.comm_stream = extra[1]        # data-parallel exchange beside the backward (the head streams are idle by then)
         bins = [[0.0, extra[0]], [0.0, extra[1]], [0.0, self.aux_stream], [0.0, None]]      # None = the main stream
         self.task_streams = [None] * self.T
@@ -1177,8 +1186,6 @@ class StepEngine:
 
     # ---- optimizer ---------------------------------------------------------------------------------
     def _optimizer(self, p: StepPlan, order: Optional[List[str]], apply_update: bool) -> None:
-        if self.grad_sync is not None:
-            self._sync_task_grads()
         names = list(self.tasks)
         main_tasks = [t for t in names if t != "domain_adv"]     # pretrain.py:137-150: PCGrad over the main tasks, then
         extra = names.index("domain_adv") if "domain_adv" in names else -1   # domain_adv_loss.backward() accumulates on top
@@ -1188,43 +1195,85 @@ class StepEngine:
                 (self.shuffle_rng or random).shuffle(order)       # reference: unseeded random.shuffle (gradient_surgery.py:43)
         idx = [names.index(t) for t in order]
         self.last_order = order
-        self._chk(self.lib.gmp_mt_pcgrad_clip_adamw(
-            self.task_grads.data_ptr(), self.P, self.T, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(),
-            _i32(idx), len(idx), names.index(main_tasks[-1]), extra, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, self.max_grad_norm,
-            self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(), self.mt_ws.data_ptr(),
-            self.mt_ws.numel(), int(apply_update), self._st()), "mt_pcgrad_clip_adamw")
+        oidx = _i32(idx)
+
+        def pcgrad(k0: int, k1: int, phases: int, stream: int) -> None:
+            self._chk(self.lib.gmp_mt_pcgrad_clip_adamw_ex(
+                self.task_grads.data_ptr(), self.P, self.T, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(),
+                oidx, len(idx), names.index(main_tasks[-1]), extra, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, self.max_grad_norm,
+                self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(), self.mt_ws.data_ptr(),
+                self.mt_ws.numel(), int(apply_update), k0, k1, phases, stream), "mt_pcgrad_clip_adamw")
+
+        if self.parts_beside_backward:
+            # PCGrad follows the backward part by part on the exchange stream (Gram / solve / combine of a part as soon as its
+            # gradients are final -- and, data parallel, averaged); only the total norm, the clip and AdamW wait for the last part
+            sync = self._part_sync()
+            k_of = self._part_tensors
+            sync.average_(self.lib, torch.cuda.current_stream(self.device), gate=(self.sync_flags.data_ptr(), self._epoch),
+                          exchange=self.grad_sync is not None,
+                          after_message=lambda parts, st: [pcgrad(k_of[b][0], k_of[b][1], 1, st) for b in parts])
+            pcgrad(0, self.K, 2, self._st())
+            return
+        if self.grad_sync is not None:
+            self._sync_task_grads()
+        pcgrad(0, self.K, 3, self._st())
+
+    def _head_slices(self):
+        out = []
+        for k, n in enumerate(self.names):
+            if n.startswith("heads."):
+                t = int(np.argmax(self.has_static[k]))
+                out.append((t * self.P + self.off[n], -(-self.numel[n] // 4) * 4))       # tensors are 4-float aligned
+        return out
+
+    def _part_sync(self):
+        """The per-task gradient matrix cut into the parts the step finishes one after the other (gmp_step_wait_grads): part 0
+        the task heads, part 1 + k backbone layer L-1-k, last part mask token + encoders -- as message slices for the exchange
+        (dist.OverlappedGradSync) and as tensor-index ranges for PCGrad (self._part_tensors)."""
+        if self._packed_sync is None:
+            from .dist import OverlappedGradSync
+            ranges: List[List[List[int]]] = [[] for _ in range(GNN_NUM_LAYERS + 2)]
+            krange: List[List[int]] = [[self.K, 0] for _ in range(GNN_NUM_LAYERS + 2)]
+            shared = [n for n in self.names if self.off[n] < self.P_shared]
+            for i, n in enumerate(shared):
+                part = GNN_NUM_LAYERS + 1
+                if n.startswith("gnn_backbone.layers."):
+                    part = GNN_NUM_LAYERS - int(n.split(".")[2])
+                end = self.off[shared[i + 1]] if i + 1 < len(shared) else self.P_shared
+                r = ranges[part]
+                if r and r[-1][1] == self.off[n]:
+                    r[-1][1] = end                                   # contiguous with the previous tensor of this part
+                else:
+                    r.append([self.off[n], end])
+                k = self.name_index[n]
+                krange[part] = [min(krange[part][0], k), max(krange[part][1], k + 1)]
+            hk = [k for k, n in enumerate(self.names) if n.startswith("heads.")]
+            krange[0] = [min(hk), max(hk) + 1] if hk else [0, 0]
+            for b, (k0, k1) in enumerate(krange):                    # every part must be one run of tensor indices
+                if k1 > k0 and sorted(self._part_of(n) for n in self.names[k0:k1]) != [b] * (k1 - k0):
+                    raise L.GnnmpError("engine: the tensors of a backward part are not contiguous in the flat layout")
+            self._part_tensors = [(k0, k1) if k1 > k0 else (0, 0) for k0, k1 in krange]
+            parts = [self._head_slices()] + [[(t * self.P + lo, hi - lo) for t in range(self.T) for lo, hi in ranges[b]]
+                                             for b in range(1, GNN_NUM_LAYERS + 2)]
+            self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
+        return self._packed_sync
+
+    @staticmethod
+    def _part_of(name: str) -> int:
+        if name.startswith("heads."):
+            return 0
+        if name.startswith("gnn_backbone.layers."):
+            return GNN_NUM_LAYERS - int(name.split(".")[2])
+        return GNN_NUM_LAYERS + 1
 
     def _sync_task_grads(self) -> None:
         """Data parallel: average the per-task gradients over ranks BEFORE PCGrad -- shared tensors once per task,
         every head once (only its own task's row is meaningful).  Native executor: in parts beside the backward
         (dist.OverlappedGradSync; GMP_DP_OVERLAP=0 falls back to one flat all-reduce after it)."""
-        head_slices = []
-        if self._packed_sync is None:
-            for k, n in enumerate(self.names):
-                if n.startswith("heads."):
-                    t = int(np.argmax(self.has_static[k]))
-                    head_slices.append((t * self.P + self.off[n], -(-self.numel[n] // 4) * 4))       # tensors are 4-float aligned
+        head_slices = self._head_slices() if self._packed_sync is None else []
         if self.native and os.environ.get("GMP_DP_OVERLAP", "1") != "0":
-            if self._packed_sync is None:
-                from .dist import OverlappedGradSync
-                # shared tensors by the part of the backward that finishes them: layer l -> part L - l, the rest -> part L + 1
-                ranges: List[List[List[int]]] = [[] for _ in range(GNN_NUM_LAYERS + 2)]
-                shared = [n for n in self.names if self.off[n] < self.P_shared]
-                for i, n in enumerate(shared):
-                    part = GNN_NUM_LAYERS + 1
-                    if n.startswith("gnn_backbone.layers."):
-                        part = GNN_NUM_LAYERS - int(n.split(".")[2])
-                    end = self.off[shared[i + 1]] if i + 1 < len(shared) else self.P_shared
-                    r = ranges[part]
-                    if r and r[-1][1] == self.off[n]:
-                        r[-1][1] = end                                   # contiguous with the previous tensor of this part
-                    else:
-                        r.append([self.off[n], end])
-                parts = [head_slices] + [[(t * self.P + lo, hi - lo) for t in range(self.T) for lo, hi in ranges[b]]
-                                         for b in range(1, GNN_NUM_LAYERS + 2)]
-                self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
-            self._packed_sync.average_(self.lib, torch.cuda.current_stream(self.device),
+            self._part_sync().average_(self.lib, torch.cuda.current_stream(self.device),
                                        gate=(self.sync_flags.data_ptr(), self._epoch) if self.use_gates else None)
             return
         if self._packed_sync is None:
@@ -1357,7 +1406,7 @@ class StepEngine:
         d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
-        d.dp_exchange = int(self.grad_sync is not None)
+        d.dp_exchange = int(self.grad_sync is not None or self.parts_beside_backward)     # publish when each part's gradients are final
         self._epoch += 1
         d.epoch, d.sync_flags = self._epoch, (self.sync_flags.data_ptr() if self.use_gates else None)
         d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)

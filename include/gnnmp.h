@@ -411,6 +411,19 @@ int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int n
                              float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
                              int32_t* flags_out, void* workspace, size_t workspace_bytes, int apply_update,
                              gmp_stream_t stream);
+/* The same in pieces, so PCGrad can follow the backward part by part: phases bit 0 = Gram / solve / combine for the tensors
+ * [k_begin, k_end) only (their final_grad, flags, step counts, norm partials), bit 1 = total norm + clip + AdamW over ALL tensors
+ * (call it once, after bit 0 has covered every tensor; same stream order or an explicit dependency in between).  Results are
+ * bitwise those of the one-shot call: every tensor's arithmetic is independent of the others up to the norm. */
+int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
+                                const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
+                                const int32_t* order_host, int n_order, int last_task, int extra_task,
+                                float* params, float* exp_avg, float* exp_avg_sq, float* steps,
+                                const float* lr, const float* wd, float beta1, float beta2, float eps,
+                                float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
+                                int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
+                                int k_begin, int k_end, int phases, gmp_stream_t stream);
+
 
 #ifdef __cplusplus
 }

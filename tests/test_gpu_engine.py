@@ -185,6 +185,27 @@ def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence(sche
         assert torch.equal(outs[0][3][k], outs[1][3][k]), k
 
 
+def test_pcgrad_part_by_part_beside_the_backward_gives_the_same_bits(monkeypatch):
+    """GMP_OPT_OVERLAP=1: Gram / solve / combine of every part of the model on the exchange stream as soon as the backward has
+    finished that part (gmp_mt_pcgrad_clip_adamw_ex), norm + clip + AdamW at the end -- bitwise the one-shot optimizer."""
+    outs = []
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("GMP_OPT_OVERLAP", overlap)
+        _, hm, eng, host, inp, gen, tasks, _ = build("s5", 73)
+        if overlap == "1" and not eng.use_gates:
+            pytest.skip("no hardware queue per stream on this box: the part-by-part path needs the gates")
+        assert eng.parts_beside_backward == (overlap == "1")
+        eng.dropout_p, eng.da_dropout, eng.grl_lambda = 0.2, 0.5, 0.004
+        g = torch.Generator().manual_seed(5)
+        for _ in range(3):
+            eng.step(inp, g, order=[t for t in tasks if t != "domain_adv"])
+        eng.check_gates()
+        torch.cuda.synchronize()
+        outs.append((eng.flat.clone(), eng.final_grad.clone(), eng.exp_avg_sq.clone(), eng.metrics.clone(), eng.steps.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("parameters", "final gradient", "second moments", "conflict counts", "step counts")):
+        assert torch.equal(a, b), what
+
+
 def test_engine_s5_step_with_domain_adversarial_term():
     """Scheme s5: PCGrad over the five main tasks, then the domain-adversarial gradient (through the gradient-reversal
     layer, lambda from the GRL scheduler) accumulates on top (pretrain.py:137-150)."""
