@@ -37,7 +37,7 @@ class LayerDesc(C.Structure):
 
 class StepDesc(C.Structure):
     _fields_ = [("N", i32), ("E", i32), ("S", i32), ("max_seg", i32), ("num_tiles", i32), ("num_tasks", i32), ("num_domains", i32),
-                ("dpad", i32), ("training", i32), ("hidden", i32), ("max_seg_edges", i32), ("dropout_p", f32), ("dp_exchange", i32), ("epoch", i32), ("seed", u64), ("sync_flags", p),
+                ("dpad", i32), ("training", i32), ("hidden", i32), ("max_seg_edges", i32), ("dropout_p", f32), ("dp_exchange", i32), ("epoch", i32), ("upload_on_aux", i32), ("seed", u64), ("sync_flags", p),
                 ("seg_ptr", p), ("seg_dom", p), ("src_row", p), ("tiles", p), ("seg_eptr", p), ("edge_index", p), ("rowmask", p),
                 ("task_row", i32 * (MAXT + 1)), ("task_seg", i32 * (MAXT + 1)),
                 ("csr", p * 6), ("csr_status", p), ("csr_ws", p), ("csr_ws_bytes", sz),

@@ -27,7 +27,7 @@ constexpr int EV_MAIN_HEADS = EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS + 1;          
 // A parked barrier packet costs every RUNNING queue ~2 us per kernel boundary (streams.hip); with the host several steps ahead
 // two or three of the four queues were parked most of the time.
 enum {
-    F_START = 0,                       // main -> aux: the step's uploads are done
+    F_START = 0,                       // main -> aux (or aux -> main, upload_on_aux): the step's uploads are done
     F_FWD = 1,                         // main -> head streams: stacked forward done
     F_HEAD_IN = 2,                     // [task] head stream -> main: input-gradient half done
     F_MAIN_HEADS = 10,                 // main -> helper: input halves of main's own heads done
@@ -342,8 +342,13 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         return GMP_OK;
     };
     // ---- CSR builds beside the encoders (they only need the uploaded indices)
-    GMP_TRY(signal(F_START, ev[0], main));
-    GMP_TRY(await(F_START, ev[0], aux));
+    if (d.upload_on_aux && aux != main) {      // the uploads came up on aux (in order there): main is the one that waits
+        GMP_TRY(signal(F_START, ev[0], aux));
+        GMP_TRY(await(F_START, ev[0], main));
+    } else {
+        GMP_TRY(signal(F_START, ev[0], main));
+        GMP_TRY(await(F_START, ev[0], aux));
+    }
     if (d.max_seg <= 8192 && d.max_seg_edges <= 24576)      // block diagonal: one workgroup per (segment, orientation)
         GMP_TRY(gmp_csr_build_segmented(d.edge_index, N, d.E, d.seg_ptr, d.seg_eptr, d.S, d.max_seg, d.max_seg_edges, d.csr[0], d.csr[1], d.csr[2], d.csr[3],
                                         d.csr[4], d.csr[5], d.csr_status, aux_));

@@ -107,6 +107,7 @@ class PackedGradSync:
         self.n, self.total = len(offs), pre[-1]
         self.table = torch.tensor(offs + pre, dtype=torch.int64, device=base.device)
         self.packed = torch.empty(self.total, dtype=torch.float32, device=base.device)
+        self._ptrs = (self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr())
         self.share = 1.0           # this message's share of the step's whole exchange (OverlappedGradSync sets it per part)
         # diagnostic (scripts/diag_dp_overlap.py): stand in for the collective's run time on a box with one GPU by a spin kernel
         # of GMP_DP_FAKE_US microseconds for the whole exchange, split over the parts by size
@@ -119,13 +120,16 @@ class PackedGradSync:
             return
         L = self._L
         st = stream_handle if stream_handle is not None else torch.cuda.current_stream(self.base.device).cuda_stream
-        L.check(L.lib().gmp_segments_pack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total, st),
-                "gmp_segments_pack")
+        lib, (pb, pp, pt) = L.lib(), self._ptrs            # (pointers cached: the launcher thread has little host time to spare)
+        rc = lib.gmp_segments_pack(pb, pp, pt, self.n, self.total, st)
+        if rc:
+            L.check(rc, "gmp_segments_pack")
         dist.all_reduce(self.packed, op=dist.ReduceOp.SUM)
         if self._fake_us > 0:
-            L.check(L.lib().gmp_spin_us(int(round(self._fake_us * self.share)), st), "gmp_spin_us")
-        L.check(L.lib().gmp_segments_unpack(self.base.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.n, self.total,
-                                            1.0 / w, st), "gmp_segments_unpack")
+            L.check(lib.gmp_spin_us(int(round(self._fake_us * self.share)), st), "gmp_spin_us")
+        rc = lib.gmp_segments_unpack(pb, pp, pt, self.n, self.total, 1.0 / w, st)
+        if rc:
+            L.check(rc, "gmp_segments_unpack")
 
 
 class OverlappedGradSync:

@@ -176,6 +176,11 @@ class StepEngine:
         self._alloc()
 
     @property
+    def upload_on_aux(self) -> bool:
+        """Native executor with gates: the step's index arrays go up on the aux stream (16 us of PCIe reads off the main stream)."""
+        return bool(self.use_gates and self.native and os.environ.get("GMP_UPLOAD_ON_AUX", "1") != "0")
+
+    @property
     def parts_beside_backward(self) -> bool:
         """(self.native may be flipped after construction -- the tests do: only the native executor publishes the part flags)"""
         return bool(self._parts_ok and self.native)
@@ -338,11 +343,10 @@ class StepEngine:
             "da_g1": (1024, DA_HIDDEN), "da_gin": (1024, H),
             "gp_in": (1024, H), "gp_y1": (1024, 2 * H), "gp_d1": (1024, 2 * H), "gp_y2": (1024, 16), "gp_g2": (1024, 16), "gp_g1": (1024, 2 * H), "gp_gin": (1024, H),
         }.items()}
-        self.lp_y2, self.lp_p, self.lp_lab, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)
+        self.lp_y2, self.lp_p, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)      # (lp_lab: upload set below)
         self.gp_y2 = f(1024, GRAPH_PROPERTY_DIM)
         self.gp_g2 = f(1024, GRAPH_PROPERTY_DIM)
         self.ntx_ws = [torch.empty(self.lib.gmp_nt_xent_grouped_workspace_bytes(self.D, 512, 128), dtype=torch.uint8, device=dev) for _ in range(2 * self.D)]
-        self.scal = torch.zeros(64, device=dev)              # device scalars: 1/size per task, NT-Xent losses ...
         # packed per-step index uploads (pinned staging)
         self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536, 4 * self.max_edges + 8 * R
         # The host runs several steps ahead of the GPU (nothing in a step syncs), so the pinned staging buffers
@@ -352,8 +356,11 @@ class StepEngine:
                        "pin64": torch.empty(self.i64_cap, dtype=torch.int64).pin_memory(),
                        "pinf": torch.empty(64 + self.KMAX, dtype=torch.float32).pin_memory(),
                        "event": None} for _ in range(self.STAGES)]
-        self.dev32 = torch.empty(self.i32_cap, dtype=torch.int32, device=dev)
-        self.dev64 = torch.empty(self.i64_cap, dtype=torch.int64, device=dev)
+        # Two sets of upload destinations, alternating by step: the native executor uploads step t+1's arrays on the AUX stream,
+        # behind aux's last work of step t and beside main's tail / optimizer, into the set step t is not using.
+        self._up_sets = [(torch.empty(self.i32_cap, dtype=torch.int32, device=dev), torch.empty(self.i64_cap, dtype=torch.int64, device=dev),
+                          torch.zeros(64, device=dev), f(self.KMAX)) for _ in range(2)]
+        self.dev32, self.dev64, self.scal, self.lp_lab = self._up_sets[0]
 
     # ------------------------------------------------------------------ host: draw + plan one step
     def draw(self, inp: StepInputs, gen: torch.Generator) -> Dict[str, object]:
@@ -790,6 +797,10 @@ class StepEngine:
         slot = self.stage[self.step_count % self.STAGES]
         if slot["event"] is not None:
             slot["event"].synchronize()                  # the copy that read this slot STAGES steps ago is done
+        # device scalars (scal: [0:8) 1/size per task, [16:48) per-domain NT-Xent sums), LP labels and the index arrays of THIS step
+        self.dev32, self.dev64, self.scal, self.lp_lab = self._up_sets[self.step_count & 1]
+        on_aux = self.upload_on_aux
+        up_stream = self.aux_stream if on_aux else torch.cuda.current_stream(self.device)
         pin32, pin64, pinf = slot["pin32"], slot["pin64"], slot["pinf"]
         o32, o64, lay32, lay64 = p.cat32.size, p.cat64.size, p.lay32, p.lay64
         pin32.numpy()[:o32] = p.cat32
@@ -806,9 +817,9 @@ class StepEngine:
         src = (C.c_void_p * 4)(pin32.data_ptr(), pin64.data_ptr(), pinf.data_ptr(), pinf.data_ptr() + 256)
         dst = (C.c_void_p * 4)(self.dev32.data_ptr(), self.dev64.data_ptr(), self.scal.data_ptr(), self.lp_lab.data_ptr())
         nbytes = (C.c_int64 * 4)(4 * o32, 8 * o64, 256, 4 * nlab)
-        self._chk(self.lib.gmp_upload(4, src, dst, nbytes, self._st()), "gmp_upload")
+        self._chk(self.lib.gmp_upload(4, src, dst, nbytes, up_stream.cuda_stream), "gmp_upload")
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(up_stream)
         slot["event"] = ev
         b32, b64 = self.dev32.data_ptr(), self.dev64.data_ptr()
         p.d32 = {k: b32 + 4 * o for k, o in lay32.items()}
@@ -1407,6 +1418,15 @@ class StepEngine:
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
         d.dp_exchange = int(self.grad_sync is not None or self.parts_beside_backward)     # publish when each part's gradients are final
+        d.upload_on_aux = int(self.upload_on_aux)
+        sc = self.scal.data_ptr()                    # this step's upload set
+        for ti, t in enumerate(self.tasks):
+            td = d.task[ti]
+            td.g_scale = sc + 4 * ti
+            if t in ("node_contrast", "graph_contrast"):
+                td.ntx_sums = sc + 4 * (16 + (0 if t == "node_contrast" else self.D))
+            if t == "link_pred":
+                td.lp_labels = self.lp_lab.data_ptr()
         self._epoch += 1
         d.epoch, d.sync_flags = self._epoch, (self.sync_flags.data_ptr() if self.use_gates else None)
         d.seed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)

@@ -84,6 +84,8 @@ typedef struct {
     float dropout_p;
     int32_t dp_exchange;          /* nonzero: record the events gmp_step_wait_grads needs (data-parallel run) */
     int32_t epoch;                /* with sync_flags: strictly increasing from call to call (>= 1) */
+    int32_t upload_on_aux;        /* nonzero: the caller enqueued this step's uploads (gmp_upload) on the AUX stream, not on main: main
+                                     waits for aux at the start instead of aux for main */
     uint64_t seed;
     int32_t* sync_flags;          /* device int32[64], zeroed once by the caller, or NULL.  Non-NULL = the caller has MEASURED that main,
                                      aux and the task streams sit on different hardware queues (gmp_streams_share_queue): cross-stream
