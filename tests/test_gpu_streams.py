@@ -64,3 +64,30 @@ def test_gate_opens_across_streams_and_waits_for_every_flag_of_its_mask():
     f = flags.cpu()
     assert int(f[3]) == 7 and int(f[5]) == 8 and int(f[63]) == 0
     assert lib.gmp_gate_wait(None, 1, 1, None, main.cuda_stream) != 0
+
+
+def test_upload_kernel_moves_pinned_pieces_bit_for_bit_and_rejects_bad_arguments():
+    """gmp_upload: up to four pinned host buffers -> device buffers by one kernel (the step's index arrays)."""
+    import ctypes as C
+    from gnn_pretraining_amd import _lib as L
+    dev = torch.device("cuda:0")
+    lib = L.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(3)
+    sizes = [4 * 12345, 2 * 777, 64, 0]                                   # elements; every piece a multiple of 16 bytes
+    src = [torch.randint(-2 ** 31, 2 ** 31 - 1, (sizes[0],), dtype=torch.int32, generator=g).pin_memory(),
+           torch.randint(-2 ** 62, 2 ** 62, (sizes[1],), dtype=torch.int64, generator=g).pin_memory(),
+           torch.randn(sizes[2], generator=g).pin_memory(), torch.zeros(4).pin_memory()]
+    dst = [torch.zeros(sizes[0] + 8, dtype=torch.int32, device=dev), torch.zeros(sizes[1] + 8, dtype=torch.int64, device=dev),
+           torch.zeros(sizes[2] + 8, device=dev), torch.full((4,), 7.0, device=dev)]
+    nbytes = (C.c_int64 * 4)(*[s.numel() * s.element_size() for s in src[:3]], 0)
+    sp = (C.c_void_p * 4)(*[s.data_ptr() for s in src])
+    dp = (C.c_void_p * 4)(*[d.data_ptr() for d in dst])
+    L.check(lib.gmp_upload(4, sp, dp, nbytes, st), "gmp_upload")
+    torch.cuda.synchronize()
+    for s, d, n in zip(src[:3], dst[:3], sizes[:3]):
+        assert torch.equal(d[:n].cpu(), s) and int(d[n:].abs().sum().item()) == 0      # nothing written past the piece
+    assert torch.equal(dst[3].cpu(), torch.full((4,), 7.0))                             # an empty piece writes nothing
+    bad = (C.c_int64 * 4)(24, 0, 0, 0)                                                   # not a multiple of 16
+    assert lib.gmp_upload(4, sp, dp, bad, st) != 0
+    assert lib.gmp_upload(5, sp, dp, nbytes, st) != 0 and lib.gmp_upload(0, sp, dp, nbytes, st) != 0
