@@ -114,7 +114,9 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES if (N, E) == PMC_SHAPE else None, "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
-            "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters}
+            "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters,
+            # for orientation only (frac above is against the 8 TB/s spec): the part's measured float4 copy rate, MI355X_MICROARCH.md
+            "measured_copy_ceiling": 6290.0, "frac_of_copy_ceiling": round(achieved / 6290.0, 4)}
 
 
 def gemm_roofline(device, rows: int = 7392):
