@@ -186,6 +186,21 @@ class _BatchNormAct(torch.autograd.Function):
         return (gu, gu if ctx.has_res else None, gg[0], gb[0]) + (None,) * 9
 
 
+_one_segment: dict = {}
+
+
+def _whole_input_segment(rows: int, device) -> Tensor:
+    """[0, rows] as a device int32 tensor, cached: built per call it was a blocking host-to-device copy in front of every
+    BatchNorm of the module path (11 per fine-tune step)."""
+    key = (rows, device)
+    t = _one_segment.get(key)
+    if t is None:
+        if len(_one_segment) > 256:
+            _one_segment.clear()
+        t = _one_segment[key] = torch.tensor([0, rows], dtype=torch.int32, device=device)
+    return t
+
+
 def batch_norm_act(x: Tensor, bn: torch.nn.BatchNorm1d, *, residual: Optional[Tensor] = None, relu: bool = True,
                    dropout_p: float = 0.0, training: Optional[bool] = None, seg_ptr: Optional[Tensor] = None,
                    max_seg_rows: Optional[int] = None) -> Tensor:
@@ -193,7 +208,7 @@ def batch_norm_act(x: Tensor, bn: torch.nn.BatchNorm1d, *, residual: Optional[Te
     (default: one segment = the whole input, i.e. exactly nn.BatchNorm1d)."""
     training = bn.training if training is None else training
     if seg_ptr is None:
-        seg_ptr = torch.tensor([0, x.size(0)], dtype=torch.int32, device=x.device)
+        seg_ptr = _whole_input_segment(x.size(0), x.device)
         max_seg_rows = x.size(0)
     if training and x.size(0) <= 1:
         raise ValueError("Expected more than 1 value per channel when training")   # torch's own check
