@@ -483,7 +483,8 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         const int64_t tiles = ((N + 63) / 64) * ((g.M + 63) / 64) * groups;
         int split = 1;
         if (workspace && tiles < 384 && max_rows >= 8 * BK_DEFAULT) {
-            split = (int)std::min<int64_t>((512 + tiles - 1) / tiles, max_rows / (4 * BK_DEFAULT));
+            static const int64_t target = getenv("GMP_TN_TARGET_BLOCKS") ? atoi(getenv("GMP_TN_TARGET_BLOCKS")) : 512;   // tuning aid
+            split = (int)std::min<int64_t>((target + tiles - 1) / tiles, max_rows / (4 * BK_DEFAULT));
             const size_t need = (size_t)groups * split * (g.M * N + g.M) * sizeof(float);
             if (split < 2 || need > workspace_bytes) split = 1;
         }
