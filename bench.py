@@ -75,11 +75,18 @@ def run_steps(engine, temperature, pool, gen, n, start=0):
     """The body of run_training (reference pretrain.py:113-155): draw artefacts, 5 task losses, per-task
     gradients, PCGrad, clip, AdamW, scheduler step -- one engine.step per optimisation step."""
     pf = StepPrefetcher(engine, (pool[(start + i) % len(pool)] for i in range(n)), gen)
-    for inp, prepared in pf:
+    advance(engine, temperature, gen, iter(pf), n)
+    return pf
+
+
+def advance(engine, temperature, gen, it, n):
+    """n steps from a running StepPrefetcher iterator (set-up, warm-up and timed steps share ONE prefetcher, so the timed
+    window starts with the host pipeline full instead of waiting for a new thread's first prepare())."""
+    for _ in range(n):
+        inp, prepared = next(it)
         engine.temperature = temperature()
         engine.step(inp, gen, prepared=prepared)
         temperature.step()
-    return pf
 
 
 def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iters: int = 20):
@@ -234,21 +241,28 @@ def main() -> None:
     # steps and the K timed steps the caller asked for follow, unchanged.
     if world > 1:
         torch.distributed.barrier()                 # ranks start stepping together (imports / pool building differ by seconds)
-    run_steps(engine, temperature, pool, gen, PRIME_STEPS)
+    total = PRIME_STEPS + a.warmup + a.steps
+    pf = StepPrefetcher(engine, (pool[i % len(pool)] for i in range(total)), gen)
+    it = iter(pf)
+    advance(engine, temperature, gen, it, PRIME_STEPS)
     from gnn_pretraining_amd import streams as ST
     log(f"streams: {ST.last_report}, cross-stream sync: {'gates' if engine.use_gates else 'events'}")
     log(f"rank {rank}/{world}: model + {POOL} step inputs resident, {PRIME_STEPS} set-up steps done, warming up {a.warmup} steps")
-    run_steps(engine, temperature, pool, gen, a.warmup, start=PRIME_STEPS)
+    advance(engine, temperature, gen, it, a.warmup)
     log("timing")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
+    busy0, wait0 = pf.busy_s, pf.wait_s
     t0 = time.perf_counter()
-    pf = run_steps(engine, temperature, pool, gen, a.steps, start=PRIME_STEPS + a.warmup)
+    advance(engine, temperature, gen, it, a.steps)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    pf.busy_s, pf.wait_s = pf.busy_s - busy0, pf.wait_s - wait0
+    for _ in it:                                    # (the prefetcher's end marker)
+        pass
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
