@@ -131,6 +131,16 @@ def hostdraw():
     return _HOSTDRAW
 
 
+def _host_tensors(b: Batch):
+    """(node ptr, edge ptr, contiguous edge_index) of a host batch as the int64 tensors the native draw module takes, built once
+    per batch object (they were rebuilt for every task of every step: 24 torch.tensor calls per step)."""
+    t = b.__dict__.get("_host_tensors")
+    if t is None:
+        t = b.__dict__["_host_tensors"] = (torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long),
+                                           b.edge_index.contiguous())
+    return t
+
+
 def _empty_views():
     z, e = np.zeros(0, dtype=np.int64), np.zeros((2, 0), dtype=np.int64)
     return (ViewArrays(z, e, np.zeros(1, dtype=np.int64), None, z), ViewArrays(z.copy(), e.copy(), np.zeros(1, dtype=np.int64), None, z.copy()))
@@ -374,8 +384,7 @@ class StepEngine:
         host = {d: inp.host[d] for d in self.domains}
         H = hostdraw()
         if H is not None:
-            args = {d: (torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long), b.edge_index.contiguous())
-                    for d, b in host.items() if b.num_graphs}
+            args = {d: _host_tensors(b) for d, b in host.items() if b.num_graphs}
         for t in self.tasks:
             if t == "node_feat_mask":
                 art[t] = {d: (_EMPTY_ART[t]() if not b.num_graphs else
@@ -400,12 +409,11 @@ class StepEngine:
             return _EMPTY_ART[t]()
         H = hostdraw()
         if t == "node_feat_mask":
-            return (H.mask_indices(torch.tensor(b.ptr_host, dtype=torch.long), gen) if H is not None else draw_mask_indices(b.ptr_host, gen)).numpy()
+            return (H.mask_indices(_host_tensors(b)[0], gen) if H is not None else draw_mask_indices(b.ptr_host, gen)).numpy()
         if t == "link_pred":
             if H is None:
                 return sample_negative_edges(b, gen).numpy()
-            return H.negative_edges(torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long),
-                                    b.edge_index.contiguous(), gen).numpy()
+            return H.negative_edges(*_host_tensors(b), gen).numpy()
         if t in ("node_contrast", "graph_contrast"):
             return self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None
         raise KeyError(t)
@@ -421,8 +429,7 @@ class StepEngine:
         H = hostdraw()
         if H is None:
             return StepEngine._draw_views_python(b, gen)
-        r = H.draw_views(torch.tensor(b.ptr_host, dtype=torch.long), torch.tensor(b.edge_ptr_host, dtype=torch.long), b.edge_index.contiguous(),
-                         int(b.x.size(1)), gen)
+        r = H.draw_views(*_host_tensors(b), int(b.x.size(1)), gen)
         out = []
         for vi in range(2):
             rows, edges, vptr, rowmask, common = (t.numpy() for t in r[5 * vi:5 * vi + 5])
