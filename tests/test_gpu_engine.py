@@ -185,6 +185,32 @@ def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence(sche
         assert torch.equal(outs[0][3][k], outs[1][3][k]), k
 
 
+@pytest.mark.parametrize("scheme", ["s4", "s5", "b2"])
+def test_gates_and_events_give_the_same_bits(monkeypatch, scheme):
+    """The native executor carries its cross-stream dependencies by gates when every stream has a hardware queue of its own
+    (per-layer gradient buffers, eps sums and mask-token sum on aux, uploads on aux, one join gate) and by events otherwise
+    (GMP_STEP_GATES=0: the guarded double buffers, everything joined on main): same kernels on the same data, so the same bits."""
+    outs = []
+    for gates in ("1", "0"):
+        monkeypatch.setenv("GMP_STEP_GATES", gates)
+        _, hm, eng, host, inp, gen, tasks, _ = build(scheme, 77)
+        if gates == "1" and not eng.use_gates:
+            pytest.skip("no hardware queue per stream on this box")
+        assert eng.use_gates == (gates == "1")
+        eng.dropout_p, eng.da_dropout, eng.grl_lambda = 0.2, 0.5, 0.004
+        g = torch.Generator().manual_seed(5)
+        for _ in range(4):
+            eng.step(inp, g, order=[t for t in tasks if t != "domain_adv"])
+        eng.check_gates()
+        torch.cuda.synchronize()
+        outs.append((eng.flat.clone(), eng.task_grads.clone(), eng.loss_sums.clone(), eng.exp_avg_sq.clone(),
+                     {k: v.clone() for k, v in hm.state_dict().items() if "running_" in k}))
+    for a, b, what in zip(outs[0][:4], outs[1][:4], ("parameters", "per-task gradients", "loss sums", "second moments")):
+        assert torch.equal(a, b), what
+    for k in outs[0][4]:
+        assert torch.equal(outs[0][4][k], outs[1][4][k]), k
+
+
 def test_pcgrad_part_by_part_beside_the_backward_gives_the_same_bits(monkeypatch):
     """GMP_OPT_OVERLAP=1: Gram / solve / combine of every part of the model on the exchange stream as soon as the backward has
     finished that part (gmp_mt_pcgrad_clip_adamw_ex), norm + clip + AdamW at the end -- bitwise the one-shot optimizer."""
