@@ -25,6 +25,37 @@ sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP: RCCL peer mappings need dmabuf IPC here
 
+
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
+    ap.add_argument("--rng", choices=["reference", "vectorized"], default=None,
+                    help="how the step's augmentation/mask/negative indices are drawn: 'reference' = the exact "
+                         "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
+                         "distributions, all graphs of a domain at once (numpy).  Default: reference when the native host module "
+                         "is built, else vectorized")
+    return ap.parse_args(argv)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves, as child processes, before this process has touched the GPU
+        # (gnn_pretraining_amd/launch.py); rank 0's result line is relayed, any failing rank fails the run, and a line that does
+        # not say n_gpus == N is an error.  Under torch.distributed.run (WORLD_SIZE set) this block is skipped.
+        from gnn_pretraining_amd.launch import run_and_relay
+        sys.exit(run_and_relay(_a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], log))
+
 import torch  # noqa: E402
 
 from gnn_pretraining_amd import dist as D, ops, synthetic as S  # noqa: E402
@@ -44,10 +75,6 @@ PMC_SHAPE = (2146816, 8068480)
 PMC_TRAFFIC_BYTES = int((1229698.6 * 2 + 2147421.6) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv (FETCH_SIZE x2: gfx950 correction)
 PRIME_STEPS = 30                # untimed set-up steps before the caller's warm-up (kernel code objects, workspaces, clocks)
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
-
-
-def log(msg: str) -> None:
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def host_cores() -> int:
@@ -181,19 +208,7 @@ def cpu_baseline(seed: int, budget_s: float = 20.0):
 
 
 def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
-    ap.add_argument("--rng", choices=["reference", "vectorized"], default=None,
-                    help="how the step's augmentation/mask/negative indices are drawn on the host: 'reference' = the exact "
-                         "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
-                         "distributions, all graphs of a domain at once (numpy).  Default: reference when the native host module "
-                         "is built, else vectorized")
-    a = ap.parse_args()
+    a = parse_args()
     # Only the result line may reach stdout: RCCL prints a banner (HIP / ROCm version, hostname, library path) on stdout when a
     # communicator is created, on every rank.  Everything printed before the result goes to stderr instead.
     sys.stdout.flush()
@@ -221,9 +236,17 @@ def main() -> None:
     device = torch.device(f"cuda:{local % ndev}")       # one rank per GPU; (rehearsals on a 1-GPU box share it over gloo)
     torch.cuda.set_device(device)
     world = D.init_from_env(os.environ.get("GMP_DIST_BACKEND"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:        # never print an n_gpus:1 line for --gpus 8
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     rank = D.rank()
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1:
+        # one collective BEFORE the engine measures which of its streams own a hardware queue: the communicator (and whatever
+        # streams / queues RCCL creates with it) exists from here on, so the calibration sees the process as it will run
+        t = torch.ones(1, device=device)
+        torch.distributed.all_reduce(t)
+        if int(t.item()) != world:
+            raise SystemExit(f"rank {rank}: the first all-reduce over {backend} returned {t.item()} for {world} ranks")
 
     seed = 42
     torch.manual_seed(seed)                        # identical replicas on every rank
@@ -239,7 +262,17 @@ def main() -> None:
     # Set-up, not measurement: 30 untimed steps load every kernel's code object, grow the lazily sized workspaces and bring the
     # clocks out of idle, so that a short run (--steps 5 --warmup 2) times the same steady state a long one does.  The W warm-up
     # steps and the K timed steps the caller asked for follow, unchanged.
+    gates_checked = None
     if world > 1:
+        # Gates are only sound between streams on hardware queues of their own, and that was measured, not promised: in a
+        # data-parallel process prove it once with the communicator live (probe steps with gates vs events, bitwise, on every
+        # rank; StepEngine.verify_gates) and fall back to events otherwise.  GMP_DP_GATES=0 / 1 skips the check.
+        force = os.environ.get("GMP_DP_GATES")
+        if force == "0":
+            engine.use_gates = False
+        elif force != "1" and engine.use_gates:
+            gates_checked = engine.verify_gates(pool[0])
+            log(f"rank {rank}: gates vs events under the live communicator: {engine.gates_verified}")
         torch.distributed.barrier()                 # ranks start stepping together (imports / pool building differ by seconds)
     total = PRIME_STEPS + a.warmup + a.steps
     pf = StepPrefetcher(engine, (pool[i % len(pool)] for i in range(total)), gen)
@@ -291,7 +324,9 @@ def main() -> None:
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
                        "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "setup_steps": PRIME_STEPS, "index_rng": a.rng,
                        "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy",
-                       "cross_stream_sync": "gates" if engine.use_gates else "events",
+                       "cross_stream_sync": "gates" if engine.use_gates else "events", "gates_verified_under_communicator": gates_checked,
+                       "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
+                       "devices_visible": torch.cuda.device_count(),
                        "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
             "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
         }

@@ -107,6 +107,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_spin_us": (C.c_int, [i32, p]),
     "gmp_gate_wait": (C.c_int, [p, C.c_uint64, i32, p, p]),
     "gmp_gate_open": (C.c_int, [p, i32, p]),
+    "gmp_gate_set_timeout": (C.c_int, [C.c_double]),
     "gmp_upload": (C.c_int, [i32, p, p, p, p]),
     "gmp_segments_pack": (C.c_int, [p, p, p, i32, i64, p]),
     "gmp_segments_unpack": (C.c_int, [p, p, p, i32, i64, f32, p]),

@@ -5,6 +5,8 @@
 // streams really run beside each other (gmp_streams_share_queue) and builds its four-stream layout from streams that do.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gnnmp_internal.h"
 
 namespace {
@@ -46,10 +48,27 @@ __global__ void gate_open_kernel(int* flag, int value) { __hip_atomic_store(flag
 
 }  // namespace
 
+// time-out of a gate in ticks of the 100 MHz wall clock: GMP_GATE_TIMEOUT_S (fractions allowed) or two minutes, until
+// gmp_gate_set_timeout replaces it (the data-parallel start-up check of the engine shortens it for its probe steps)
+static unsigned long long ticks_of(double seconds) {
+    if (!(seconds > 0.0)) seconds = 120.0;
+    if (seconds > 3600.0) seconds = 3600.0;
+    return (unsigned long long)(seconds * 1e8);
+}
+static std::atomic<unsigned long long>& gate_ticks() {
+    static std::atomic<unsigned long long> t{ticks_of(getenv("GMP_GATE_TIMEOUT_S") ? atof(getenv("GMP_GATE_TIMEOUT_S")) : 120.0)};
+    return t;
+}
+extern "C" int gmp_gate_set_timeout(double seconds) {
+    if (!(seconds > 0.0) || seconds > 3600.0) return gmp::fail(GMP_ERR_ARG, "gate_set_timeout: %g s not in (0, 3600]", seconds);
+    gate_ticks().store(ticks_of(seconds));
+    return GMP_OK;
+}
+
 extern "C" int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t st) {
     if (!flags) return gmp::fail(GMP_ERR_ARG, "gate_wait: null flags");
     if (!mask) return GMP_OK;
-    static const unsigned long long ticks = (unsigned long long)(getenv("GMP_GATE_TIMEOUT_S") ? atof(getenv("GMP_GATE_TIMEOUT_S")) : 120.0) * 100000000ull;   // 100 MHz wall clock
+    const unsigned long long ticks = gate_ticks().load();
     hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(GATE_FLAGS), 0, (hipStream_t)st, (const int*)flags, (unsigned long long)mask, want, (int*)err, ticks);
     return gmp::check_launch("gate_wait_kernel");
 }

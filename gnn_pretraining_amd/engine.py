@@ -1307,6 +1307,55 @@ class StepEngine:
             raise L.GnnmpError("engine: a cross-stream gate timed out (streams sharing a hardware queue, or a tool serialising "
                                "kernels?) -- rerun with GMP_STEP_GATES=0")
 
+    def verify_gates(self, inp: "StepInputs", steps: int = 2, timeout_s: float = 5.0) -> bool:
+        """Start-up self-check of the gates in the process as it now is (call it AFTER the process group exists: a communicator
+        brings streams and queues of its own, and the stream -> hardware-queue calibration this engine was built on predates
+        nothing it has not seen).  `steps` probe steps run from the current state with gates (short time-out), then -- from the
+        same state, with the same draws and dropout seeds -- with events; gates stay on only when no gate timed out and
+        parameters, per-task gradients, losses and running statistics are bitwise equal, on EVERY rank.  The engine's state is
+        restored afterwards.  Collective: all ranks of a data-parallel job must call it together."""
+        if not self.use_gates:
+            return False
+        import torch.distributed as tdist
+        dev = self.device
+        bufs = [self.flat, self.exp_avg, self.exp_avg_sq, self.steps, self.enc_rm, self.enc_rv, self.loss_sums]
+        bufs += [b for n, b in self.model.named_buffers() if "running_" in n and not n.startswith("input_encoders.")]
+        saved = [b.clone() for b in bufs]
+        host_state = (self.step_count, self._bn_calls, list(self._bn_calls_dom), self._nprng, dict(self.host_ms))
+        tasks = [t for t in self.tasks if t != "domain_adv"]
+        self._chk(self.lib.gmp_gate_set_timeout(float(timeout_s)), "gate_set_timeout")
+        outs, timed_out = [], False
+        try:
+            for gates in (True, False):
+                self.use_gates = gates
+                for b, s in zip(bufs, saved):
+                    b.copy_(s)
+                self.step_count = host_state[0]
+                self._nprng = None
+                g = torch.Generator().manual_seed(12345)
+                for _ in range(steps):
+                    self.step(inp, g, order=tasks)
+                torch.cuda.synchronize(dev)
+                if gates:
+                    timed_out = int(self.sync_flags[63].item()) != 0
+                    self.sync_flags[63] = 0
+                outs.append([self.flat.clone(), self.task_grads.clone(), self.loss_sums.clone()] + [b.clone() for b in bufs[4:]])
+        finally:
+            for b, s in zip(bufs, saved):
+                b.copy_(s)
+            self.step_count, self._bn_calls, self._bn_calls_dom, self._nprng = host_state[0], host_state[1], host_state[2], host_state[3]
+            self.host_ms.update(host_state[4])
+            self._chk(self.lib.gmp_gate_set_timeout(float(os.environ.get("GMP_GATE_TIMEOUT_S", "120"))), "gate_set_timeout")
+        ok = (not timed_out) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+            ok = bool(t.item())
+        self.use_gates = ok
+        self.gates_verified = {"ok": ok, "timed_out": timed_out, "steps": steps}
+        torch.cuda.synchronize(dev)
+        return ok
+
     def losses(self) -> Dict[str, float]:
         self.check_gates()
         sums = self.loss_sums[:self.T].tolist()

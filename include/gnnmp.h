@@ -364,6 +364,10 @@ int gmp_spin_us(int microseconds, gmp_stream_t stream);
  * streams on different hardware queues (gmp_streams_share_queue): in one in-order queue a gate ahead of its opener never opens. */
 int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t stream);
 int gmp_gate_open(int32_t* flag, int value, gmp_stream_t stream);
+/* Time-out of the gates enqueued from now on (default: GMP_GATE_TIMEOUT_S seconds, else 120; fractions allowed).  A gate that
+ * times out sets *err and lets its stream go on; the engine's data-parallel start-up check (StepEngine.verify_gates) runs
+ * its probe steps with a short one so that a stream layout that cannot carry gates shows within seconds. */
+int gmp_gate_set_timeout(double seconds);
 
 /* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one
