@@ -10,6 +10,8 @@
 // registers one K-step ahead of the MFMAs.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "gnnmp_internal.h"
 
@@ -145,6 +147,8 @@ struct GemmArgs {
     // one-thread "open the gate" launch (5-6 us on a busy chip) between a producer and the GEMM that follows it anyway
     int* sig_flag;
     int sig_value;
+    int vecC;             // C (+ every group's coff) 16-byte aligned and ldc % 4 == 0: the pipelined kernel stores float4 row pieces
+    int nt_store;         // pipelined kernel: non-temporal output stores
 };
 
 thread_local int* t_sig_flag = nullptr;
@@ -154,6 +158,8 @@ inline void take_signal(GemmArgs& g) {
     g.sig_value = t_sig_value;
     t_sig_flag = nullptr;
 }
+
+#include "gemm_pipe.h"      // namespace g2, nested in this anonymous namespace (its kernels take GemmArgs: internal linkage throughout)
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int BK, bool FAST>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
@@ -375,6 +381,82 @@ void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st, bool fa
 #undef GMP_GEMM_LAUNCH
 }
 
+// ---- the pipelined kernel (gemm_pipe.h): when it applies and with which tile ----------------------------------------
+// GMP_GEMM_IMPL=old keeps every problem on gemm_kernel (A/B aid); GMP_GEMM_PIPE_TILE=0..3 forces 128x128 / 64x128 / 128x64 / 64x64.
+constexpr int PIPE_TILES[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
+
+template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
+int launch_pipe_cfg(const GemmArgs& g, int tiles_m, int tiles_n, int z, hipStream_t st) {
+    using C = g2::Cfg<TM, TN, A_KC, B_KC, STAGES>;
+    auto kern = g2::gemm_pipe_kernel<TM, TN, A_KC, B_KC, STAGES>;
+    static bool attr_set = false;            // a workgroup may ask for up to 160 KiB of LDS once the function says so
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+            return gmp::fail(GMP_ERR_LAUNCH, "gemm_pipe: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), 1, (unsigned)z), dim3(g2::THREADS), C::LDS_BYTES, st, g, tiles_m, tiles_n);
+    return gmp::check_launch("gemm_pipe_kernel");
+}
+
+// LDS ring depth: 4 stages everywhere (128x128: 4 x 32 KB, one block per CU; 64x64: 4 x 16 KB, two blocks per CU).  A 3-stage 64x64
+// ring (three blocks per CU) is 1 us faster alone and slower inside the step (1.53 against 1.45 ms): GMP_GEMM_PIPE_STAGES=3
+template <bool A_KC, bool B_KC>
+int launch_pipe_tile(int tile, const GemmArgs& g, int64_t rows, int z, hipStream_t st) {
+    const int TMs = PIPE_TILES[tile][0], TNs = PIPE_TILES[tile][1];
+    const int tiles_m = (int)((rows + 64 * TMs - 1) / (64 * TMs)), tiles_n = (int)((g.N + 64 * TNs - 1) / (64 * TNs));
+    const char* e = getenv("GMP_GEMM_PIPE_STAGES");
+    const int deep = e ? atoi(e) : 0;
+    switch (tile) {
+        case 0: return launch_pipe_cfg<2, 2, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+        case 1: return launch_pipe_cfg<1, 2, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+        case 2: return launch_pipe_cfg<2, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+        default: return deep == 3 ? launch_pipe_cfg<1, 1, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
+                                  : launch_pipe_cfg<1, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+    }
+}
+
+int launch_pipe(int mode, int tile, const GemmArgs& g_in, int64_t rows, int z, hipStream_t st) {
+    GemmArgs g = g_in;
+    const char* nt = getenv("GMP_GEMM_NT_STORE");
+    g.nt_store = nt && nt[0] == '1';     // off by default: measured in the step, the consumer's L2 misses cost more (1.62 vs 1.46 ms)
+    if (mode == GMP_GEMM_NT) return launch_pipe_tile<true, true>(tile, g, rows, z, st);
+    if (mode == GMP_GEMM_NN) return launch_pipe_tile<true, false>(tile, g, rows, z, st);
+    return launch_pipe_tile<false, false>(tile, g, rows, z, st);
+}
+
+// (read per call, not cached: scripts/bench_gemm_pipe.py flips them inside one process for interleaved A/B rounds)
+inline bool pipe_enabled() {
+    const char* e = getenv("GMP_GEMM_IMPL");
+    return !(e && !strcmp(e, "old"));
+}
+inline int pipe_forced_tile() {
+    const char* e = getenv("GMP_GEMM_PIPE_TILE");
+    return e ? atoi(e) : -1;
+}
+
+// Tile choice.  Measured on MI355X (scripts/bench_gemm_pipe.py, profiles/README.md round 2): at the step's shapes (M ~ 7 k rows,
+// 256 <-> 512, K = 256 .. 768) the 64x64 tile wins or ties everywhere -- alone (24-25 us against 25.7 for 128x128 at N = 512,
+// 23 against 24-40 at N = 256, 141 against 151-167 us at the 37 k-row link-prediction shape) and inside the step, where its
+// 64 KB of LDS let two blocks share a CU beside the other streams' kernels (1.42 against 1.46 ms per step).  The main loop of every
+// tile is MFMA-bound at the clock the chip holds (2.0 us per 32-deep K-step of 128x128 = 4,096 MFMA cycles at ~2.05 GHz); what
+// separates them is the fixed prologue / epilogue, which smaller, staggered blocks hide better.  The larger tiles stay available
+// through GMP_GEMM_PIPE_TILE (0 = 128x128, 1 = 64x128, 2 = 128x64) for shapes this was not measured on.
+int pipe_pick_tile(int64_t rows, int64_t N, int64_t z) {
+    (void)rows; (void)N; (void)z;
+    if (pipe_forced_tile() >= 0 && pipe_forced_tile() < 4) return pipe_forced_tile();
+    return 3;
+}
+
+// operand conditions of the LDS-DMA loaders: 16-byte aligned bases and leading dimensions; k-contiguous operands need whole
+// 32-deep K-steps; k-major operands are fetched in quads of 4 rows / columns (clamped by quads)
+bool pipe_ok(int mode, const GemmArgs& g) {
+    if (!pipe_enabled() || !g.vecA || !g.vecB) return false;
+    if (mode == GMP_GEMM_NT) return g.K >= 64 && g.K % g2::BK == 0;
+    if (mode == GMP_GEMM_NN) return g.K >= 64 && g.K % g2::BK == 0 && g.N % 4 == 0 && g.N >= 4;
+    return g.M % 4 == 0 && g.M >= 4 && g.N % 4 == 0 && g.N >= 4;
+}
+
 }  // namespace
 
 namespace gmp {
@@ -413,6 +495,7 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
     GemmArgs g{A, B, bias, C, M, N, K, lda, ldb, ldc, alpha, accumulate, relu, 1, nullptr,
                (lda % 4 == 0) && aligned16(A), (ldb % 4 == 0) && aligned16(B)};
     take_signal(g);
+    g.vecC = (ldc % 4 == 0) && aligned16(C);
     const size_t want = gmp_gemm_f32_workspace_bytes(mode, M, N, K);
     if (want && workspace && workspace_bytes >= want) {
         g.splitk = (int)(want / ((size_t)M * N * sizeof(float)));
@@ -426,6 +509,12 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
     (void)t12864;
     if (g.splitk == 1) tile = t128 >= 4096 ? 2 : 0;     // measured on MI355X: 64x64 wins until the grid is many waves deep
     if (forced >= 0 && forced <= 2 && g.splitk == 1) tile = forced;
+    // large row counts (the backbone's layer GEMMs, the link-prediction scorer): the LDS-DMA pipelined kernel
+#ifdef GMP_PIPE_DEBUG
+    if (getenv("GMP_PIPE_NOSTORE")) g.accumulate |= 0x100;
+#endif
+    if (mode != GMP_GEMM_TN && g.splitk == 1 && M >= 1024 && N >= 64 && pipe_ok(mode, g))
+        return launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, 1, st);
     static const bool nofast = getenv("GMP_GEMM_NOFAST") != nullptr;
     // with split-K (TN) slices start at multiples of BK inside [0,K): the fast loader's k handling covers that
     const bool fast = !nofast && fast_ok<BK_DEFAULT>(mode, g, M);
@@ -459,6 +548,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     g.vecB = (ldb % 4 == 0) && aligned16(B);
     g.groups = groups;
     g.gsplit = 1;
+    g.vecC = (ldc % 4 == 0) && aligned16(C);
     take_signal(g);
     g.asum = mode == GMP_GEMM_TN ? a_colsum : nullptr;
     int64_t max_rows = 0;
@@ -473,12 +563,45 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         g.coff[i] = c_off_host ? c_off_host[i] : 0;
         g.asumoff[i] = a_colsum_off_host ? a_colsum_off_host[i] : (int64_t)i * M_tn;
         if ((g.boff[i] % 4) || (g.coff[i] % 4)) g.vecB = 0;
+        if (g.coff[i] % 4) g.vecC = 0;
     }
     hipStream_t st = (hipStream_t)stream;
     if (mode == GMP_GEMM_TN) {
         g.M = M_tn;          // output rows = columns of A (k-major A: lda >= M_tn); the reduction runs over the group's rows
         g.K = 0;
         if (g.M == 0) return GMP_OK;
+        // long reductions (the per-task weight gradients of the stacked backward): the pipelined kernel; tile and the number of
+        // row slices per group are chosen together for the shortest grid (rounds of 256 CUs x K-steps per block x MFMAs per step)
+        // (only for callers that hand over a workspace, i.e. opted into row slices: the grouped NT-Xent does not, and stays
+        // bit-identical to its single-problem form on gemm_kernel)
+        if (workspace && max_rows >= 256 && pipe_ok(mode, g)) {
+            int best_tile = 0, best_split = 1;
+            int64_t best_cost = -1;
+            for (int c = 0; c < 4; ++c) {
+                if (c != pipe_pick_tile(g.M, N, groups)) continue;
+                const int64_t bm = 64 * PIPE_TILES[c][0], bn = 64 * PIPE_TILES[c][1];
+                const int64_t tiles = ((g.M + bm - 1) / bm) * ((N + bn - 1) / bn) * groups;
+                for (int sp = 1; sp <= 32; ++sp) {
+                    if (sp > 1 && (!workspace || (size_t)groups * sp * (g.M * N + g.M) * sizeof(float) > workspace_bytes)) break;
+                    const int64_t steps = (max_rows + g2::BK - 1) / g2::BK, per = (steps + sp - 1) / sp;
+                    if (sp > 1 && per < 2) break;
+                    // + 2 K-steps per round for the prologue / epilogue of a block, + the reduce pass over the slices
+                    const int64_t cost = ((tiles * sp + 255) / 256) * (per + 2) * PIPE_TILES[c][0] * PIPE_TILES[c][1] + (sp > 1 ? sp / 2 + 2 : 0);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_tile = c; best_split = sp; }
+                }
+            }
+            g.gsplit = best_split;
+            if (best_split > 1) {
+                g.gpart = (float*)workspace;
+                g.gasum_part = g.gpart + (size_t)groups * best_split * g.M * N;
+            }
+            if (int rc = launch_pipe(mode, best_tile, g, g.M, groups * best_split, st)) return rc;
+            if (best_split > 1) {
+                int blocks = (int)std::min<int64_t>((g.M * N + g.M + 255) / 256, 256);
+                hipLaunchKernelGGL(grouped_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, g);
+            }
+            return gmp::check_launch("gemm_pipe_kernel (grouped)");
+        }
         // few output tiles x long reductions: slice every group's rows over several blocks when a workspace is given
         const int64_t tiles = ((N + 63) / 64) * ((g.M + 63) / 64) * groups;
         int split = 1;
@@ -506,6 +629,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         g.M = 0;
         static const bool nofast_g2 = getenv("GMP_GEMM_NOFAST") != nullptr;
         g.K = K;
+        if (max_rows >= 1024 && N >= 64 && pipe_ok(mode, g)) return launch_pipe(mode, pipe_pick_tile(max_rows, N, groups), g, max_rows, groups, st);
         launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((max_rows + 63) / 64), (unsigned)groups), st,
                             !nofast_g2 && fast_ok<BK_DEFAULT>(mode, g, 1));
     }
