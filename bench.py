@@ -189,6 +189,7 @@ def cpu_baseline(seed: int, budget_s: float = 20.0):
     cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
+    random.seed(seed)                 # PyG's negative sampler (oracle/augment.py) draws from Python's global `random`
     gen = torch.Generator().manual_seed(seed)
     domains, tasks = PT.PRETRAIN_DOMAINS[SCHEME], PT.ACTIVE_TASKS[SCHEME]
     model = OM.PretrainableGNN(torch.device("cpu"), domains, tasks)

@@ -15,6 +15,7 @@
 #include <ATen/core/DistributionsHelper.h>
 
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -82,43 +83,146 @@ at::Tensor mask_indices(at::Tensor ptr, at::Generator gen) {
     return to_tensor(out);
 }
 
-// pretrain/tasks.py sample_negative_edges
-at::Tensor negative_edges(at::Tensor ptr, at::Tensor eptr, at::Tensor edge_index, at::Generator gen) {
-    check_ptrs(ptr, eptr, edge_index);
-    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
-    std::vector<int64_t> os, od, perm, cand;
-    std::vector<char> adj;
-    {
-        pybind11::gil_scoped_release nogil;
-        std::lock_guard<std::mutex> lock(impl->mutex_);
-        Rng rng{impl};
-        const int64_t *p = ptr.data_ptr<int64_t>(), *ep = eptr.data_ptr<int64_t>(), *src = edge_index.data_ptr<int64_t>();
-        const int64_t E = edge_index.size(1);
-        const int64_t* dst = src + E;
-        for (int64_t gidx = 0; gidx + 1 < ptr.numel(); ++gidx) {
-            const int64_t s = p[gidx], n = p[gidx + 1] - s, es = ep[gidx], ee = ep[gidx + 1];
-            adj.assign((size_t)(n * n), 0);
-            for (int64_t e = es; e < ee; ++e) {
-                const int64_t a = src[e] - s, b = dst[e] - s;
-                adj[(size_t)(a * n + b)] = 1;
-                adj[(size_t)(b * n + a)] = 1;
+// ---- pretrain/tasks.py sample_negative_edges: PyG's batched_negative_sampling, drawn from PYTHON's random ---------------------
+// PyG's sampler (torch_geometric/utils/_negative_sampling.py `sample`) calls random.sample(range(population), k) on Python's
+// global Mersenne Twister, so the native twin carries a CPython-compatible MT19937: same state words (random.getstate()[1]),
+// getrandbits(k) = genrand_uint32() >> (32 - k), _randbelow_with_getrandbits and both branches of random.sample (pool for
+// n <= 21 + 4 ** ceil(log(3k, 4)), rejection set otherwise) -- CPython 3.10 Lib/random.py.  Given an equal state it returns the
+// negatives the Python code returns and leaves the equal state behind (tests/test_hostdraw.py).
+struct PyRandom {
+    uint32_t mt[624];
+    int pos = 624;
+
+    void setstate(const at::Tensor& st) {
+        TORCH_CHECK(st.dtype() == at::kLong && st.numel() == 625 && st.is_contiguous(), "PyRandom: 625 int64 state words expected");
+        const int64_t* v = st.data_ptr<int64_t>();
+        for (int i = 0; i < 624; ++i) mt[i] = (uint32_t)v[i];
+        TORCH_CHECK(v[624] >= 0 && v[624] <= 624, "PyRandom: bad state position");
+        pos = (int)v[624];
+    }
+    at::Tensor getstate() const {
+        at::Tensor t = at::empty({625}, at::kLong);
+        int64_t* v = t.data_ptr<int64_t>();
+        for (int i = 0; i < 624; ++i) v[i] = mt[i];
+        v[624] = pos;
+        return t;
+    }
+    uint32_t next32() {          // genrand_uint32 of _randommodule.c
+        constexpr int N = 624, M = 397;
+        constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+        if (pos >= N) {
+            int kk;
+            uint32_t y;
+            for (kk = 0; kk < N - M; ++kk) {
+                y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+                mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
             }
-            for (int64_t i = 0; i < n; ++i) adj[(size_t)(i * n + i)] = 1;
-            cand.clear();
-            for (int64_t f = 0; f < n * n; ++f)
-                if (!adj[(size_t)f]) cand.push_back(f);
-            const int64_t k = std::min<int64_t>(ee - es, (int64_t)cand.size());
-            if (k == 0) continue;
-            rng.randperm((int64_t)cand.size(), perm);
+            for (; kk < N - 1; ++kk) {
+                y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+                mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+            }
+            y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+            mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+            pos = 0;
+        }
+        uint32_t y = mt[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    // Random._randbelow_with_getrandbits(n), 0 < n < 2^32
+    int64_t randbelow(int64_t n) {
+        int k = 0;
+        for (int64_t v = n; v; v >>= 1) ++k;            // n.bit_length()
+        uint32_t r = next32() >> (32 - k);
+        while ((int64_t)r >= n) r = next32() >> (32 - k);
+        return (int64_t)r;
+    }
+    // random.sample(range(n), k)
+    void sample_range(int64_t n, int64_t k, std::vector<int64_t>& out, std::vector<int64_t>& pool, std::vector<char>& seen) {
+        out.resize((size_t)k);
+        double setsize = 21;
+        if (k > 5) setsize += std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
+        if ((double)n <= setsize) {
+            pool.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i;
             for (int64_t i = 0; i < k; ++i) {
-                const int64_t f = cand[(size_t)perm[(size_t)i]];
-                os.push_back(f / n + s);
-                od.push_back(f % n + s);
+                const int64_t j = randbelow(n - i);
+                out[(size_t)i] = pool[(size_t)j];
+                pool[(size_t)j] = pool[(size_t)(n - i - 1)];
+            }
+        } else {
+            seen.assign((size_t)n, 0);
+            for (int64_t i = 0; i < k; ++i) {
+                int64_t j = randbelow(n);
+                while (seen[(size_t)j]) j = randbelow(n);
+                seen[(size_t)j] = 1;
+                out[(size_t)i] = j;
             }
         }
     }
-    return to_tensor2(os, od);
-}
+
+    // sample_negative_edges(batch, rng) for a whole domain batch
+    at::Tensor negative_edges(at::Tensor ptr, at::Tensor eptr, at::Tensor edge_index) {
+        check_ptrs(ptr, eptr, edge_index);
+        std::vector<int64_t> os, od, rnd, pool, neg;
+        std::vector<char> is_edge, taken, seen;
+        {
+            pybind11::gil_scoped_release nogil;
+            const int64_t *p = ptr.data_ptr<int64_t>(), *ep = eptr.data_ptr<int64_t>(), *src = edge_index.data_ptr<int64_t>();
+            const int64_t E = edge_index.size(1), num_neg = E;
+            const int64_t* dst = src + E;
+            for (int64_t gidx = 0; gidx + 1 < ptr.numel(); ++gidx) {
+                const int64_t s = p[gidx], n = p[gidx + 1] - s, es = ep[gidx], ee = ep[gidx + 1];
+                if (n < 2) continue;
+                const int64_t pop = n * n - n;
+                TORCH_CHECK(pop < (int64_t(1) << 31), "hostdraw: graph too large for the negative sampler");
+                // to_undirected(pos) without self loops, as slots of the n (n - 1) index space: slot(i, j) = i (n - 1) + j - (i < j)
+                is_edge.assign((size_t)pop, 0);
+                int64_t nidx = 0;
+                auto mark = [&](int64_t a, int64_t b) {
+                    if (a == b) return;
+                    const size_t slot = (size_t)(a * (n - 1) + b - (a < b ? 1 : 0));
+                    if (!is_edge[slot]) { is_edge[slot] = 1; ++nidx; }
+                };
+                for (int64_t e = es; e < ee; ++e) {
+                    mark(src[e] - s, dst[e] - s);
+                    mark(dst[e] - s, src[e] - s);
+                }
+                if (nidx >= pop) continue;
+                const double prob = 1.0 - (double)nidx / (double)pop;
+                const int64_t size = (int64_t)(1.1 * (double)num_neg / prob);
+                neg.clear();
+                taken.assign((size_t)pop, 0);
+                for (int attempt = 0; attempt < 3; ++attempt) {
+                    if (pop <= size) {
+                        rnd.resize((size_t)pop);
+                        for (int64_t i = 0; i < pop; ++i) rnd[(size_t)i] = i;
+                    } else {
+                        sample_range(pop, size, rnd, pool, seen);
+                    }
+                    for (int64_t v : rnd)
+                        if (!is_edge[(size_t)v] && !taken[(size_t)v]) neg.push_back(v);
+                    for (int64_t v : neg) taken[(size_t)v] = 1;      // np.isin(rnd, neg_idx) of the NEXT try (duplicates within one
+                    if ((int64_t)neg.size() >= num_neg) {              // try cannot occur: random.sample draws without replacement)
+                        neg.resize((size_t)num_neg);
+                        break;
+                    }
+                }
+                for (int64_t v : neg) {
+                    const int64_t r = v / (n - 1);
+                    int64_t c = v % (n - 1);
+                    if (r <= c) ++c;
+                    os.push_back(r + s);
+                    od.push_back(c + s);
+                }
+            }
+        }
+        return to_tensor2(os, od);
+    }
+};
 
 // engine.StepEngine._draw_views over pretrain/augmentations.py _augment_one: two views of every graph of a domain batch.
 // Returns, per view: rows (kept nodes, batch numbering), edges [2, e'] (view numbering), ptr [B+1], rowmask (bit c set = column c
@@ -212,6 +316,10 @@ std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor e
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("mask_indices", &mask_indices, "per-graph randperm(n)[:max(1, int(.15 n))] + offset for n >= 3");
-    m.def("negative_edges", &negative_edges, "per graph: as many uniform non-edges as it has COO entries");
+    pybind11::class_<PyRandom>(m, "PyRandom", "CPython-compatible MT19937 stream (random.getstate()[1] words) for PyG's negative sampler")
+        .def(pybind11::init<>())
+        .def("setstate", &PyRandom::setstate)
+        .def("getstate", &PyRandom::getstate)
+        .def("negative_edges", &PyRandom::negative_edges, "batched_negative_sampling(to_undirected(pos), batch, num_neg_samples=E) of a domain batch");
     m.def("draw_views", &draw_views, "two augmented views of every graph of a batch, as index arrays");
 }

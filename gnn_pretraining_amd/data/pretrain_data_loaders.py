@@ -55,12 +55,27 @@ class BalancedMultiDomainSampler:
 
 
 class SequentialGraphLoader:
-    """torch_geometric DataLoader(dataset, batch_size) as the reference builds it: no shuffle, last batch kept."""
+    """torch_geometric DataLoader(dataset, batch_size, generator=generator) as the reference builds it (:65): no shuffle, last
+    batch kept.  One detail of torch's DataLoader is part of the contract because the reference hands its SHARED generator to the
+    validation loaders: every `iter(loader)` draws a 64-bit base seed from `loader.generator`
+    (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__: `torch.empty((), dtype=torch.int64).random_(generator=...)`),
+    i.e. once per (task, domain) pass of run_evaluation (pretrain.py:214), interleaved with that pass's mask / view / negative
+    draws.  `draw_base_seed` makes that draw; `batches()` lists the batches without it (for callers that order the draws
+    themselves, run_evaluation_engine)."""
 
-    def __init__(self, dataset: GraphDataset, batch_size: int) -> None:
-        self.dataset, self.batch_size = dataset, batch_size
+    def __init__(self, dataset: GraphDataset, batch_size: int, generator: Optional[torch.Generator] = None) -> None:
+        self.dataset, self.batch_size, self.generator = dataset, batch_size, generator
+
+    def draw_base_seed(self) -> None:
+        if self.generator is not None:
+            torch.empty((), dtype=torch.int64).random_(generator=self.generator)
+
+    def batches(self) -> List[Batch]:
+        return [self.dataset.collate(torch.arange(s, min(s + self.batch_size, len(self.dataset))))
+                for s in range(0, len(self.dataset), self.batch_size)]
 
     def __iter__(self) -> Iterator[Batch]:
+        self.draw_base_seed()
         for s in range(0, len(self.dataset), self.batch_size):
             yield self.dataset.collate(torch.arange(s, min(s + self.batch_size, len(self.dataset))))
 
@@ -74,7 +89,7 @@ def _split_dataset(domain_name: str, split: str, root: Optional[Path]) -> GraphD
 
 
 def create_val_data_loader(domain_name: str, generator: torch.Generator, root: Optional[Path] = None) -> SequentialGraphLoader:
-    return SequentialGraphLoader(_split_dataset(domain_name, "val", root), BATCH_SIZE)
+    return SequentialGraphLoader(_split_dataset(domain_name, "val", root), BATCH_SIZE, generator)
 
 
 def create_train_data_loader(domains: List[str], generator: torch.Generator, root: Optional[Path] = None) -> BalancedMultiDomainSampler:

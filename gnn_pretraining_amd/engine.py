@@ -154,11 +154,15 @@ _EMPTY_ART = {"node_feat_mask": lambda: np.zeros(0, dtype=np.int64), "link_pred"
 class StepEngine:
     def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
-                 grad_sync=None, rng_mode: str = "reference", native: bool = True) -> None:
+                 grad_sync=None, rng_mode: str = "reference", native: bool = True, neg_rng: Optional[random.Random] = None) -> None:
         self.native = native       # True: csrc/step.hip enqueues the step; False: the same launches one by one from Python
         if rng_mode not in ("reference", "vectorized"):
             raise ValueError("rng_mode must be 'reference' or 'vectorized'")
         self.rng_mode, self._nprng = rng_mode, None
+        # Link-prediction negatives: PyG's sampler draws from Python's `random` (the global, unseeded module in the reference), never
+        # from the shared torch generator (pretrain/tasks.py sample_negative_edges).  The engine keeps a stream of its own.
+        self.neg_rng = neg_rng if neg_rng is not None else random.Random(0x9E3779B1 * (seed + 1))
+        self._neg_native = None
         for t in tasks:
             if t not in SUPPORTED_TASKS:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
@@ -391,9 +395,7 @@ class StepEngine:
                               H.mask_indices(args[d][0], gen).numpy() if H is not None else draw_mask_indices(b.ptr_host, gen).numpy())
                           for d, b in host.items()}
             elif t == "link_pred":
-                art[t] = {d: (_EMPTY_ART[t]() if not b.num_graphs else
-                              H.negative_edges(*args[d], gen).numpy() if H is not None else sample_negative_edges(b, gen).numpy())
-                          for d, b in host.items()}
+                art[t] = {d: (_EMPTY_ART[t]() if not b.num_graphs else self._negatives(b)) for d, b in host.items()}
             elif t in ("node_contrast", "graph_contrast"):
                 art[t] = {d: (_EMPTY_ART[t]() if b.num_graphs == 0 else
                               self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None)
@@ -411,9 +413,7 @@ class StepEngine:
         if t == "node_feat_mask":
             return (H.mask_indices(_host_tensors(b)[0], gen) if H is not None else draw_mask_indices(b.ptr_host, gen)).numpy()
         if t == "link_pred":
-            if H is None:
-                return sample_negative_edges(b, gen).numpy()
-            return H.negative_edges(*_host_tensors(b), gen).numpy()
+            return self._negatives(b)
         if t in ("node_contrast", "graph_contrast"):
             return self._draw_views(b, gen) if (t == "node_contrast" or b.num_graphs >= 2) else None
         raise KeyError(t)
@@ -421,6 +421,25 @@ class StepEngine:
     @staticmethod
     def empty_art(t: str):
         return _EMPTY_ART[t]()
+
+    def _negatives(self, b: Batch) -> np.ndarray:
+        """batched_negative_sampling(to_undirected(pos), batch, num_neg_samples=E) of one domain batch from the engine's Python-random
+        stream: the native CPython-compatible MT19937 (csrc_host/hostdraw.cpp PyRandom, seeded from self.neg_rng's state at first
+        use and the owner of the stream from then on) when the module is built, pretrain/tasks.py otherwise -- same negatives."""
+        H = hostdraw()
+        if H is None or not hasattr(H, "PyRandom"):
+            return sample_negative_edges(b, self.neg_rng).numpy()
+        if self._neg_native is None:
+            self._neg_native = H.PyRandom()
+            self._neg_native.setstate(torch.tensor(self.neg_rng.getstate()[1], dtype=torch.long))
+        return self._neg_native.negative_edges(*_host_tensors(b)).numpy()
+
+    def sync_neg_rng(self) -> random.Random:
+        """Write the native stream's state back into self.neg_rng (checkpointing / tests) and return it."""
+        if self._neg_native is not None:
+            st = self.neg_rng.getstate()
+            self.neg_rng.setstate((st[0], tuple(int(v) for v in self._neg_native.getstate().tolist()), st[2]))
+        return self.neg_rng
 
     @staticmethod
     def _draw_views(b: Batch, gen: torch.Generator) -> Tuple[ViewArrays, ViewArrays]:
@@ -558,8 +577,10 @@ class StepEngine:
                     out[d] = np.flatnonzero(rank < k[ng])
                 elif t == "link_pred":
                     cptr = st["cand_ptr"]
-                    want = np.minimum(np.diff(st["eptr"]), np.diff(cptr))
-                    pick = [cptr[g] + rng.choice(cptr[g + 1] - cptr[g], size=want[g], replace=False)
+                    # PyG applies num_neg_samples = E of the WHOLE batch to every graph: min(E, its non-edges) each
+                    want = np.minimum(int(st["eptr"][-1]), np.diff(cptr))
+                    pick = [cptr[g] + (np.arange(want[g]) if want[g] == cptr[g + 1] - cptr[g] else
+                                       rng.choice(cptr[g + 1] - cptr[g], size=want[g], replace=False))
                             for g in range(len(n)) if want[g] > 0]
                     out[d] = st["cand"][:, np.concatenate(pick)] if pick else np.zeros((2, 0), dtype=np.int64)
                 else:

@@ -196,16 +196,24 @@ def run_evaluation_engine(state: StepState, engine, val_loaders, generator: torc
     forward per task -- 21 passes instead of 105 per epoch on the four-domain schemes.
     With the reference's draw order (rng_mode "reference") every draw of the evaluation is made FIRST, in the reference's
     task-major order over domains over batches (pretrain.py:211-221), and handed to the passes, so the shared generator is
-    consumed exactly as the reference consumes it; with vectorised draws each pass draws for itself."""
+    consumed exactly as the reference consumes it -- including the base seed torch's DataLoader draws from it at every
+    `for batch in val_loader` (one per task and domain, ahead of that pass's draws; SequentialGraphLoader.draw_base_seed);
+    with vectorised draws each pass draws for itself."""
     from ..constants import DOMAIN_DIMENSIONS
     from ..engine import StepInputs
     from ..graph import Batch
     state.model.eval()
     tasks = list(state.tasks)
-    batches = {d: list(loader) for d, loader in val_loaders.items()}
+    batches = {d: (loader.batches() if hasattr(loader, "batches") else list(loader)) for d, loader in val_loaders.items()}
     arts = None
     if engine.rng_mode == "reference":
-        arts = {t: {d: [engine.draw_task(t, b, generator) for b in batches[d]] for d in batches} for t in tasks if t in engine.DRAWN_TASKS}
+        arts = {}
+        for t in tasks:                                  # every task iterates every loader once, drawing or not
+            for d in batches:
+                if hasattr(val_loaders[d], "draw_base_seed"):
+                    val_loaders[d].draw_base_seed()
+                if t in engine.DRAWN_TASKS:
+                    arts.setdefault(t, {})[d] = [engine.draw_task(t, b, generator) for b in batches[d]]
     per_dt: Dict[str, Dict[str, float]] = {}
     for d in batches:
         acc = {t: [] for t in tasks}

@@ -32,29 +32,61 @@ class TwoViews(NamedTuple):
     common2: Tensor
 
 
-def sample_negative_edges(batch: Batch, generator: torch.Generator) -> Tensor:
-    """Benchmark rule of SURVEY.md section 8d standing in for PyG's batched_negative_sampling
-    (tasks.py:107-111, whose draws come from Python `random`/NumPy and cannot be replayed): per
-    graph, as many negatives as it has directed COO entries, uniform without replacement over
-    ordered pairs (i, j), i != j, not adjacent in either direction."""
+def negative_sampling_local(ei: np.ndarray, n: int, num_neg: int, rng) -> np.ndarray:
+    """torch_geometric.utils.negative_sampling(edge_index, n, num_neg) for ONE graph in local numbering ("sparse" method,
+    not bipartite, force_undirected=False; PyG >= 2.3, requirements.txt:3).  `ei` = to_undirected edges [2, E] without
+    duplicates.  Index space: the n (n - 1) ordered pairs (i, j), i != j (self loops are never sampled); when the over-sample
+    size int(1.1 * num_neg / prob) reaches that population every non-edge is returned, in index order, with no random draw;
+    otherwise `rng.sample(range(population), size)` -- Python's random, as PyG -- up to three times.  -> [2, k] int64."""
+    pop = n * n - n
+    row, col = ei[0], ei[1]
+    keep = row != col
+    row, col = row[keep], col[keep]
+    idx = row * (n - 1) + (col - (row < col))
+    if idx.size >= pop:
+        return np.zeros((2, 0), dtype=np.int64)
+    prob = 1.0 - idx.size / pop
+    size = int(1.1 * num_neg / prob)
+    neg = None
+    for _ in range(3):
+        rnd = np.arange(pop, dtype=np.int64) if pop <= size else np.asarray(rng.sample(range(pop), size), dtype=np.int64)
+        m = np.isin(rnd, idx)
+        if neg is not None:
+            m |= np.isin(rnd, neg)
+        rnd = rnd[~m]
+        neg = rnd if neg is None else np.concatenate([neg, rnd])
+        if neg.size >= num_neg:
+            neg = neg[:num_neg]
+            break
+    r = neg // (n - 1)
+    c = neg % (n - 1)
+    c = c + (r <= c)
+    return np.stack([r, c])
+
+
+def sample_negative_edges(batch: Batch, rng=None) -> Tensor:
+    """The reference's negatives (tasks.py:105-110): batched_negative_sampling(to_undirected(pos_edges), batch.batch,
+    num_neg_samples=pos_edges.size(1)) -- PyG applies num_neg_samples to every graph of the batch on its own, so graph i gives
+    min(E_batch, n_i (n_i - 1) - E_i) negatives (for TUDataset-sized graphs: ALL its non-edges, ~8x its positives at 8 graphs per
+    batch).  Drawn from Python's `random` (`rng`: anything with .sample; default the global module, as PyG does), NOT from the
+    shared torch generator.  Restated from PyG's published source; parity unpinned (no fixture in the reference)."""
+    import random as _random
+    rng = rng or _random
     host = batch.host()
     ei = host.edge_index.numpy()
+    num_neg = int(ei.shape[1])
     outs = []
     for g in range(host.num_graphs):
         s, e = host.ptr_host[g], host.ptr_host[g + 1]
         es, ee = host.edge_ptr_host[g], host.edge_ptr_host[g + 1]
         n = e - s
-        adj = np.zeros((n, n), dtype=bool)
-        loc = ei[:, es:ee] - s
-        adj[loc[0], loc[1]] = True
-        adj[loc[1], loc[0]] = True
-        np.fill_diagonal(adj, True)
-        cand = np.flatnonzero(~adj.ravel())
-        k = min(ee - es, cand.size)
-        if k == 0:
+        if n < 2:
             continue
-        pick = cand[torch.randperm(cand.size, generator=generator)[:k].numpy()]
-        outs.append(np.stack([pick // n, pick % n]) + s)
+        loc = ei[:, es:ee] - s
+        und = np.unique(np.concatenate([loc[0] * n + loc[1], loc[1] * n + loc[0]]))      # to_undirected: both directions, coalesced
+        neg = negative_sampling_local(np.stack([und // n, und % n]), n, num_neg, rng)
+        if neg.shape[1]:
+            outs.append(neg + s)
     if not outs:
         return torch.empty(2, 0, dtype=torch.long)
     return torch.from_numpy(np.concatenate(outs, axis=1))
@@ -115,8 +147,11 @@ class LinkPredictionTask(BasePretrainTask):
     sigmoid outputs (torch's -100 log clamp); total = sum / sum(K)."""
     name = "link_pred"
 
-    def draw(self, domain_batches, generator):
-        return {d: sample_negative_edges(b, generator) for d, b in domain_batches.items()}
+    py_rng = None        # the Python-random stream PyG's sampler draws from; None = the global `random` module, as in the reference
+
+    def draw(self, domain_batches, generator, rng=None):
+        """(the shared torch generator is NOT advanced: PyG's sampler draws from Python's `random`)"""
+        return {d: sample_negative_edges(b, rng or self.py_rng) for d, b in domain_batches.items()}
 
     def loss(self, domain_batches, neg_edges):
         dev = self.model.device

@@ -70,8 +70,9 @@ def nfm_loss(model: PretrainableGNN, batches, mask_idx: Dict[str, Tensor]):
 
 
 # ------------------------------------------------------------------ LP (a9) --
-def lp_draw(batches, gen) -> Dict[str, Tensor]:
-    return {d: sample_negative_edges(b, gen) for d, b in batches.items()}
+def lp_draw(batches, gen=None, rng=None) -> Dict[str, Tensor]:
+    """PyG's negative sampler draws from Python's `random` (rng; default the global module), never from the torch generator."""
+    return {d: sample_negative_edges(b, rng) for d, b in batches.items()}
 
 
 def lp_loss(model: PretrainableGNN, batches, neg_edges: Dict[str, Tensor]):
@@ -179,13 +180,14 @@ class Task:
     def __init__(self, name: str, model: PretrainableGNN, temperature=None, grl=None) -> None:
         self.name, self.model, self.temperature, self.grl = name, model, temperature, grl
         self.last_artifacts = None
+        self.py_rng = None          # link_pred: the Python-random stream PyG's sampler draws from (None: the global `random` module)
 
     def draw(self, batches, gen):
         n = self.name
         if n == "node_feat_mask":
             return nfm_draw(self.model, batches, gen)
         if n == "link_pred":
-            return lp_draw(batches, gen)
+            return lp_draw(batches, gen, self.py_rng)
         if n == "node_contrast":
             return nc_draw(batches, gen)
         if n == "graph_contrast":

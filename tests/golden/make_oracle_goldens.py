@@ -6,7 +6,8 @@ here): this pins the oracle against drift, it does not pin it to the reference.
     python tests/golden/make_oracle_goldens.py          # rewrites tests/golden/oracle_step.json
 
 Inputs: scheme s4, torch seed 123, batches from gnn_pretraining_amd.synthetic.pretrain_step_batches(Generator(123)),
-dropout off, the oracle's own draws from the same generator, PCGrad order fixed."""
+dropout off, the oracle's own draws from the same generator (link-prediction negatives: PyG's sampler draws from Python's
+`random`, here random.Random(123)), PCGrad order fixed."""
 import json
 import os
 import sys
@@ -36,6 +37,8 @@ def run():
     batches = {d: to_oracle(b) for d, b in host.items()}
     temp, grl = OTr.TemperatureScheduler(462 * 50), OTr.GRLScheduler(50, 462)
     otasks = OTk.instantiate_tasks(model, tasks, grl, temp)
+    import random
+    otasks["link_pred"].py_rng = random.Random(SEED)
     opt, bal = OTr.make_optimizer(model, tasks), OTr.AdaptiveLossBalancer()
     for g in opt.param_groups:
         g["lr"] *= 1000

@@ -191,6 +191,26 @@ def test_val_loader_is_sequential_batches_of_32(processed):
     _same_batch(batches[0], store.collate(val[:32]))
 
 
+def test_val_loader_draws_the_dataloader_base_seed_like_torch(processed):
+    """The reference's validation loaders are torch DataLoaders on the SHARED generator (pretrain_data_loaders.py:65): every
+    iteration start draws a base seed from it.  Generator state after two passes over our loader == after two passes over a
+    real torch DataLoader of the same length on an equally seeded generator (and batches() makes no draw)."""
+    from torch.utils.data import DataLoader
+    ga, gb = _gen(9), _gen(9)
+    ours = create_val_data_loader("NCI1", ga, processed)
+    theirs = DataLoader(list(range(len(ours.dataset))), batch_size=32, generator=gb)
+    for _ in range(2):
+        assert len(list(ours)) == len(list(theirs))
+    assert torch.equal(ga.get_state(), gb.get_state())
+    assert not torch.equal(ga.get_state(), _gen(9).get_state())
+    before = ga.get_state()
+    assert len(ours.batches()) == len(ours)
+    assert torch.equal(ga.get_state(), before)
+    ours.draw_base_seed()
+    next(iter(theirs))
+    assert torch.equal(ga.get_state(), gb.get_state())
+
+
 def test_finetune_loaders(processed):
     g = _gen(0)
     gl = create_finetune_data_loader("ENZYMES", "train", 32, g, processed)

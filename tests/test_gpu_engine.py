@@ -363,7 +363,7 @@ def test_engine_step_matches_the_committed_oracle_fixture():
     hm.device = DEV
     hm.to(DEV)
     hm.train()
-    eng = StepEngine(hm, tasks, domains, DEV, seed=1, rng_mode="reference")
+    eng = StepEngine(hm, tasks, domains, DEV, seed=1, rng_mode="reference", neg_rng=random.Random(want["seed"]))   # the fixture's stream
     eng.dropout_p = 0.0
     host = S.pretrain_step_batches(gen, domains)
     assert {d: b.num_nodes for d, b in host.items()} == want["nodes"]
@@ -399,12 +399,18 @@ def test_engine_validation_consumes_the_generator_like_the_reference_loop(tmp_pa
     hm = PretrainableGNN(DEV, cfg.pretrain_domains, cfg.active_tasks)
     state = PT.StepState(hm, cfg, steps_per_epoch=10, epochs=2)
     eng = StepEngine(hm, cfg.active_tasks, cfg.pretrain_domains, DEV, seed=3, rng_mode="reference", max_rows=65536, max_edges=524288)
-    g0 = torch.Generator().manual_seed(11)
-    loaders = {d: create_val_data_loader(d, g0, tmp_path) for d in cfg.pretrain_domains}
+    # the reference builds its validation loaders on the SAME generator the tasks draw from (pretrain.py:295): every
+    # `for batch in val_loader` then draws torch's DataLoader base seed from it, once per task and domain
     ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
-    m_mod = PT.run_evaluation(state, loaders, ga, DEV)
+    loaders_a = {d: create_val_data_loader(d, ga, tmp_path) for d in cfg.pretrain_domains}
+    loaders_b = {d: create_val_data_loader(d, gb, tmp_path) for d in cfg.pretrain_domains}
+    if "link_pred" in state.tasks:                                    # PyG's negatives come from Python's random: equal streams
+        state.tasks["link_pred"].py_rng, eng.neg_rng = random.Random(8), random.Random(8)
+    m_mod = PT.run_evaluation(state, loaders_a, ga, DEV)
     state.balancer.step_count -= 1                                   # both calls advance the warm-up counter once
-    m_eng = PT.run_evaluation_engine(state, eng, loaders, gb, DEV)
+    m_eng = PT.run_evaluation_engine(state, eng, loaders_b, gb, DEV)
+    untouched = torch.Generator().manual_seed(5)
+    assert not torch.equal(ga.get_state(), untouched.get_state())
     assert torch.equal(ga.get_state(), gb.get_state())
     assert set(m_mod) == set(m_eng)
     for k, v in m_mod.items():

@@ -67,6 +67,8 @@ def _planner(mode, scheme="s4"):
     e = StepEngine.__new__(StepEngine)                # host-side methods only: no device, no library
     e.tasks, e.domains = PT.ACTIVE_TASKS[scheme], PT.PRETRAIN_DOMAINS[scheme]
     e.max_rows, e.max_edges, e.S_MAX, e.KMAX, e.rng_mode, e._nprng = 16384, 131072, 64, 131072, mode, None
+    import random
+    e.neg_rng, e._neg_native = random.Random(99), None
     return e
 
 
@@ -105,11 +107,13 @@ def test_vectorized_draws_are_valid_artefacts():
             per = np.bincount(np.searchsorted(np.asarray(b.ptr_host), idx, side="right") - 1, minlength=len(n))
             assert len(np.unique(idx)) == len(idx)
             assert np.array_equal(per, np.where(n >= 3, np.maximum(1, (n * .15).astype(int)), 0))
-            # LP: as many negatives as directed edges per graph, all non-adjacent ordered pairs inside the graph
+            # LP (PyG batched_negative_sampling, num_neg_samples = E of the batch applied per graph): min(E, own non-edges) negatives
+            # per graph, all non-adjacent ordered pairs (i != j) inside the graph
             neg = art["link_pred"][d]
             g_of = lambda v: np.searchsorted(np.asarray(b.ptr_host), v, side="right") - 1
             assert np.array_equal(g_of(neg[0]), g_of(neg[1])) and (neg[0] != neg[1]).all()
-            assert np.array_equal(np.bincount(g_of(neg[0]), minlength=len(n)), np.diff(np.asarray(b.edge_ptr_host)))
+            eg = np.diff(np.asarray(b.edge_ptr_host))
+            assert np.array_equal(np.bincount(g_of(neg[0]), minlength=len(n)), np.minimum(ei.shape[1], n * (n - 1) - eg))
             und = set(map(tuple, ei.T)) | set(map(tuple, ei[::-1].T))
             assert not (set(map(tuple, neg.T)) & und) and len(set(map(tuple, neg.T))) == neg.shape[1]
             for t in ("node_contrast", "graph_contrast"):

@@ -42,8 +42,6 @@ def test_native_draws_equal_the_python_reference_order(seed):
         g1, g2 = _gens(seed)
         assert torch.equal(H.mask_indices(ptr, g1), draw_mask_indices(b.ptr_host, g2))
         assert torch.equal(g1.get_state(), g2.get_state())
-        assert torch.equal(H.negative_edges(ptr, eptr, ei, g1), sample_negative_edges(b, g2))
-        assert torch.equal(g1.get_state(), g2.get_state())
         for _ in range(3):                                                       # several rounds: coins fall differently
             got = H.draw_views(ptr, eptr, ei, b.x.size(1), g1)
             want = StepEngine._draw_views_python(b, g2)
@@ -67,11 +65,16 @@ def test_engine_draw_uses_the_native_module_and_matches_python(monkeypatch):
     gen = torch.Generator().manual_seed(3)
     inp = _Inp(S.pretrain_step_batches(gen, e.domains))
     g1, g2 = _gens(9)
+    import random
+    e.neg_rng = random.Random(4)
     art_native = e.draw(inp, g1)
+    native_state = e.sync_neg_rng().getstate()
     monkeypatch.setattr("gnn_pretraining_amd.engine._HOSTDRAW", None)
     monkeypatch.setattr("gnn_pretraining_amd.engine._HOSTDRAW_TRIED", True)
+    e.neg_rng, e._neg_native = random.Random(4), None
     art_python = e.draw(inp, g2)
     assert torch.equal(g1.get_state(), g2.get_state())
+    assert e.neg_rng.getstate() == native_state          # the Python-random stream of the negatives too
     for t in art_python:
         for d in art_python[t]:
             a, b = art_native[t][d], art_python[t][d]
@@ -81,3 +84,29 @@ def test_engine_draw_uses_the_native_module_and_matches_python(monkeypatch):
                     assert (va.rowmask is None) == (vb.rowmask is None) and (va.rowmask is None or np.array_equal(va.rowmask, vb.rowmask))
             else:
                 assert np.array_equal(np.asarray(a), np.asarray(b)), (t, d)
+
+
+def _sparse_big_batch(gen):
+    """large graphs with few edges: the over-sample is far below the population, random.sample takes its rejection-set branch"""
+    return Batch.from_data_list([S.random_graph(gen, 4, 100.0, 20.0), S.random_graph(gen, 4, 126.0, 30.0), S.random_graph(gen, 4, 60.0, 10.0)])
+
+
+@pytest.mark.parametrize("seed", [0, 7, 2024])
+def test_native_negative_sampler_replays_pythons_random(seed):
+    """PyG's batched_negative_sampling draws from Python's random.sample: the native CPython-compatible MT19937 must return the
+    negatives of pretrain/tasks.py sample_negative_edges for an equal random.Random state and leave the equal state behind --
+    over small graphs (every non-edge, no draw), mid-sized ones (pool branch of random.sample) and sparse large ones (set branch)."""
+    import random
+    H = hostdraw()
+    gen = torch.Generator().manual_seed(seed)
+    r_py, nat = random.Random(seed), H.PyRandom()
+    nat.setstate(torch.tensor(r_py.getstate()[1], dtype=torch.long))
+    drew = False
+    for b in _batches() + [_sparse_big_batch(gen), S.domain_batch(gen, 21, 32)]:
+        before = r_py.getstate()
+        want = sample_negative_edges(b, r_py)
+        drew |= r_py.getstate() != before
+        got = nat.negative_edges(*_args(b))
+        assert torch.equal(got, want)
+        assert tuple(nat.getstate().tolist()) == r_py.getstate()[1]
+    assert drew                                           # at least one batch needed random draws
