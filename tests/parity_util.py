@@ -59,3 +59,93 @@ def assert_grad_close(got, want, gmax, what=""):
     e_max = d.abs().max().item() / max(want.abs().max().item(), floor, 1e-30)
     e_l2 = d.norm().item() / max(want.norm().item(), floor * want.numel() ** 0.5, 1e-30)
     assert e_max <= 1e-1 and e_l2 <= 1e-2, f"{what}: max-norm rel {e_max:.3e}, L2 rel {e_l2:.3e}"
+
+
+def engine_gate_tapes(eng, plan, art):
+    """The ReLU gates the HIP engine used in its last step, as one oracle.gates tape per task, in the oracle's call order
+    (oracle/tasks.py: per task, per domain [per view]: encoder ReLU, then inner / outer ReLU of the five GIN layers, then the
+    task head's ReLU(s) for that domain; link prediction: the signs of hs - hd first).  Read from the activations the step leaves behind: h[0] (encoder output; rows the
+    node-feature-masking task overwrote with the mask token come from its saved targets), r1[l] / h[l + 1] per layer, the
+    heads' y1 buffers.  Dropout must be off (a dropped unit reads as a closed gate)."""
+    from oracle.gates import GateTape
+    N = plan.N
+    enc = (eng.h[0][:N] > 0).cpu()
+    if "node_feat_mask" in eng.tasks and plan.nfm_rows[-1]:
+        idx = torch.from_numpy(plan.a64["nfm_idx"]).long()
+        enc[idx] = (eng.hd["nfm_tgt"][:idx.numel()] > 0).cpu()
+    inner = [(eng.r1[l][:N] > 0).cpu() for l in range(len(eng.r1))]
+    outer = [(eng.h[l + 1][:N] > 0).cpu() for l in range(len(eng.r1))]
+    segs = {}
+    for si, (ti, di) in enumerate(zip(plan.seg_task, plan.seg_dom)):
+        segs.setdefault((ti, di), []).append(si)
+
+    def backbone(si, with_layers=True):
+        a, b = plan.seg_ptr[si], plan.seg_ptr[si + 1]
+        out = [enc[a:b]]
+        if with_layers:
+            for l in range(len(inner)):
+                out += [inner[l][a:b], outer[l][a:b]]
+        return out
+
+    tapes = {}
+    for ti, t in enumerate(eng.tasks):
+        m = []
+        lp_off = 0
+        for di, d in enumerate(eng.domains):
+            ss = segs.get((ti, di), [])
+            if t == "node_feat_mask":
+                r0, r1 = plan.nfm_rows[di], plan.nfm_rows[di + 1]
+                m += backbone(ss[0], with_layers=r1 > r0)             # no masked node: the oracle stops after the encoder
+                if r1 > r0:
+                    m.append((eng.hd["nfm_y1"][r0:r1] > 0).cpu())
+            elif t == "link_pred":
+                k = eng_lp_count(eng, plan, art, d)
+                m += backbone(ss[0])
+                e = torch.from_numpy(plan.a64["lp_edges"][:, lp_off:lp_off + k]).long().to(eng.h[-1].device)
+                m.append(torch.sign(eng.h[-1][e[0]] - eng.h[-1][e[1]]).to(torch.int8).cpu())      # sign(hs - hd): the |.| feature's kink
+                m.append((eng.hd["lp_y1"][lp_off:lp_off + k] > 0).cpu())
+                lp_off += k
+            elif t == "node_contrast":
+                for si in ss:
+                    m += backbone(si)
+                n = plan.nc_n[di]
+                if n:
+                    r0 = plan.nc_rows[di]
+                    m += [(eng.hd["nc_y1"][r0:r0 + n] > 0).cpu(), (eng.hd["nc_y1"][r0 + n:r0 + 2 * n] > 0).cpu()]
+            elif t == "graph_contrast":
+                if not ss:
+                    continue
+                for si in ss:
+                    m += backbone(si)
+                B, r0 = plan.gc_n[di], plan.gc_rows[di]
+                m += [(eng.hd["gc_y1"][r0:r0 + B] > 0).cpu(), (eng.hd["gc_y1"][r0 + B:r0 + 2 * B] > 0).cpu()]
+            elif t == "graph_prop":
+                m += backbone(ss[0])
+                m.append((eng.hd["gp_y1"][plan.gp_rows[di]:plan.gp_rows[di + 1]] > 0).cpu())
+            elif t == "domain_adv":
+                m += backbone(ss[0])
+                a, b = plan.seg_ptr[ss[0]], plan.seg_ptr[ss[0] + 1]
+                g0 = sum(1 for s in plan.a32["da_ptr"][:-1] if s < a)
+                g1 = sum(1 for s in plan.a32["da_ptr"][:-1] if s < b)
+                m.append((eng.hd["da_y1"][g0:g1] > 0).cpu())
+        tapes[t] = GateTape(m)
+    return tapes
+
+
+def eng_lp_count(eng, plan, art, d):
+    """edges scored for domain d by the link-prediction head: its positives + the drawn negatives"""
+    import numpy as np
+    pos = eng.last_inputs.host[d].edge_index.size(1)
+    return pos + np.asarray(art["link_pred"][d]).shape[1]
+
+
+def assert_grad_tight(got, want, gmax, what="", tol=2e-4):
+    """Flip-free gradient parity (both sides used the same ReLU gates): max |got - want| <= tol * max(max|want|, 1e-3 * largest
+    gradient of the task) -- the floor only covers analytically-zero gradients (a bias in front of a train-mode BatchNorm), where
+    both sides hold rounding noise; a scalar (GINConv.eps: one cancelling sum of N * 256 products) is held against gmax."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    floor = gmax if want.numel() == 1 else 1e-3 * gmax
+    e = (got - want).abs().max().item() / max(want.abs().max().item(), floor, 1e-30)
+    assert e <= tol, f"{what}: max rel err {e:.3e} > {tol}"
+    return e

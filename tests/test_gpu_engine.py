@@ -15,7 +15,8 @@ from gnn_pretraining_amd.engine import StepEngine, StepInputs                   
 from gnn_pretraining_amd.models import PretrainableGNN                             # noqa: E402
 from gnn_pretraining_amd.pretrain import pretrain as PT                            # noqa: E402
 from oracle import models as OM, tasks as OTk, train as OTr                        # noqa: E402
-from parity_util import assert_close, assert_grad_close, copy_state, set_dropout, to_oracle   # noqa: E402
+from parity_util import (assert_close, assert_grad_close, assert_grad_tight, copy_state, engine_gate_tapes, set_dropout,   # noqa: E402
+                         to_oracle)
 from test_gpu_modules import perturb_bn                                            # noqa: E402
 
 DEV = torch.device("cuda:0")
@@ -112,6 +113,82 @@ def test_engine_losses_task_gradients_and_running_stats(scheme, seed, rng_mode):
             assert_close(hsd[k], v, 1e-4, f"buffer {k}")
         if k.endswith("num_batches_tracked"):
             assert int(hsd[k]) == int(v), (k, int(hsd[k]), int(v))
+
+
+def _to_double(b):
+    from oracle import graph_ops as OG
+    return OG.Batch(b.x.double(), b.edge_index, b.batch, b.ptr, b.edge_ptr, b.y, None if b.graph_properties is None else b.graph_properties.double())
+
+
+def _art_double(o_art):
+    out = {}
+    for t, a in o_art.items():
+        out[t] = {d: (None if v is None else OTk.TwoViews(_to_double(v.v1), _to_double(v.v2), v.common1, v.common2) if isinstance(v, OTk.TwoViews) else v)
+                  for d, v in a.items()}
+    return out
+
+
+@pytest.mark.parametrize("scheme,seed", [("s4", 141), ("s1", 142), ("b3", 143), ("b2", 144), ("s5", 145), ("b4", 146), ("s3", 147)])
+def test_engine_gradients_with_shared_relu_gates(scheme, seed):
+    """Step-level gradient parity WITHOUT the ReLU-flip allowance.  Two correct fp32 implementations gate a pre-activation that
+    lies within rounding of zero differently, and one such flip moves a gradient by ~1e-3 -- the reason the test above accepts
+    1e-2.  Here the oracle is run with the gates the HIP step actually used (oracle/gates.py: every ReLU, and sign(hs - hd) of the
+    link-prediction |hs - hd| feature; read back from the activations the step leaves behind), so no discontinuity is left, for every scheme family of src/pretrain/pretrain.py:43-52 (s1 =
+    BASELINE.json configs[0], b3 = NC only).  Bars, per task and per parameter tensor (max-norm, relative to the tensor's largest
+    entry, floored at 1e-3 of the task's largest gradient for analytically-zero tensors):
+      * against the oracle in fp32: 2.5e-4 -- except where the oracle's OWN fp32 run sits further than that from its fp64 run (the
+        link-prediction gradients into the backbone: ~60 cancelling per-edge terms per node), where
+      * the HIP gradient must be no further from the fp64 oracle than 3x the fp32 oracle is, and never further than 1e-3 from it;
+      * losses 1e-4."""
+    import copy
+    import oracle.gates as OGt
+    om, hm, eng, host, inp, gen, tasks, domains = build(scheme, seed)
+    art = eng.draw(inp, gen)
+    eng.temperature, eng.grl_lambda = 0.41, 0.006
+    eng.step(inp, gen, art=art, order=[t for t in tasks if t != "domain_adv"], apply_update=False)
+    got_losses = eng.losses()
+    tapes = engine_gate_tapes(eng, eng.last_plan, art)
+    o_batches = {d: to_oracle(b) for d, b in host.items()}
+    o_art = oracle_artefacts(art, host)
+    om64 = copy.deepcopy(om).double()
+    runs = [(om, OTk.instantiate_tasks(om, tasks, lambda: 0.006, lambda: 0.41), o_batches, o_art),
+            (om64, OTk.instantiate_tasks(om64, tasks, lambda: 0.006, lambda: 0.41), {d: _to_double(b) for d, b in o_batches.items()}, _art_double(o_art))]
+    worst32, worst64, flips, gates, beyond = 0.0, 0.0, 0, 0, 0
+    for name in tasks:
+        grads = []
+        for (model, otasks, batches, arts) in runs:
+            model.zero_grad(set_to_none=True)
+            tape = OGt.GateTape(tapes[name].masks)
+            with OGt.use_tape(tape):
+                lo, _ = otasks[name].loss(batches, arts.get(name))
+            assert tape.done(), f"{name}: {tape.pos} of {len(tape.masks)} gates consumed"
+            assert abs(got_losses[name] - lo.item()) <= 1e-4 * abs(lo.item()), (name, got_losses[name], lo.item())
+            lo.backward()
+            grads.append({n: p.grad for n, p in model.named_parameters()})
+            if model is om:
+                flips += tape.flips
+                gates += sum(m.numel() for m in tape.masks)
+        g32, g64 = grads
+        gmax = max(g.abs().max().item() for g in g64.values() if g is not None)
+        for n, want in g64.items():
+            if want is None:
+                assert g32[n] is None
+                continue
+            got = eng.task_gradient(name, n)
+            floor = gmax if want.numel() == 1 else 1e-3 * gmax
+            scale = max(want.abs().max().item(), floor, 1e-30)
+            e_hip32 = (got.cpu().double() - g32[n].double()).abs().max().item() / scale
+            e_hip64 = (got.cpu().double() - want).abs().max().item() / scale
+            e_o32 = (g32[n].double() - want).abs().max().item() / scale
+            worst32, worst64 = max(worst32, e_hip32), max(worst64, e_hip64)
+            if e_hip32 > 2.5e-4:
+                beyond += 1
+                assert e_o32 > 6e-5, f"{scheme} {name}: grad {n}: {e_hip32:.2e} from the fp32 oracle, which itself is only {e_o32:.2e} from fp64"
+            assert e_hip64 <= max(2.5e-4, 3 * e_o32) and e_hip64 <= 1e-3, \
+                f"{scheme} {name}: grad {n}: HIP {e_hip64:.2e} from the fp64 oracle, fp32 oracle {e_o32:.2e}"
+    print(f"{scheme}: worst gradient error {worst32:.2e} vs the fp32 oracle, {worst64:.2e} vs fp64; {beyond} tensors beyond 2.5e-4 of the fp32 "
+          f"oracle; {flips} of {gates} gates differ between the two implementations")
+    assert flips <= 1e-5 * gates + 20                   # the gates agree except within rounding of zero
 
 
 def test_engine_full_s4_step_matches_oracle_step():
