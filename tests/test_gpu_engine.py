@@ -205,9 +205,16 @@ def test_engine_full_s4_step_matches_oracle_step():
     eng.lr.mul_(1000)
     eng.temperature = temp()
     o_batches = {d: to_oracle(b) for d, b in host.items()}
-    lo, _, to, mo = OTr.train_step(om, otasks, oopt, obal, grl, temp, o_batches, gen, artifacts=oracle_artefacts(art, host), order=order)
+    # the engine first: the oracle then runs the same step with the ReLU / sign gates the HIP forward used (oracle/gates.py), so
+    # the comparison of the UPDATE is not blurred by gates that two fp32 implementations resolve differently
+    import oracle.gates as OGt
     eng.step(inp, gen, art=art, order=order)
     got = eng.losses()
+    tapes = engine_gate_tapes(eng, eng.last_plan, art)
+    tape = OGt.GateTape([m for t in tasks for m in tapes[t].masks])
+    with OGt.use_tape(tape):
+        lo, _, to, mo = OTr.train_step(om, otasks, oopt, obal, grl, temp, o_batches, gen, artifacts=oracle_artefacts(art, host), order=order)
+    assert tape.done()
     for n in tasks:
         assert abs(got[n] - lo[n].item()) <= 1e-4 * abs(lo[n].item()), n
     after_o, after_h = om.state_dict(), hm.state_dict()
@@ -217,9 +224,12 @@ def test_engine_full_s4_step_matches_oracle_step():
     assert "heads.link_pred.predictor.mlp.0.weight" not in moved_o      # a17 quirk: neither first-shuffled nor last task
     num = sum(((after_h[k].cpu() - after_o[k]).double() ** 2).sum().item() for k in moved_o)
     den = sum(((after_o[k] - before[k]).double() ** 2).sum().item() for k in moved_o)
-    assert (num / den) ** 0.5 <= 2e-2, f"relative update error {(num / den) ** 0.5:.3e}"
     conf, proj = eng.metrics.tolist()
-    assert abs(proj - mo["gradient_surgery/total_projections"]) <= 140
+    print(f"relative update error {(num / den) ** 0.5:.3e}; projections {proj} vs {mo['gradient_surgery/total_projections']}")
+    # what is left: PCGrad's own discontinuity (a projection happens when a per-tensor dot product is < 0; pairs within rounding of
+    # orthogonal resolve differently) and Adam's 1/sqrt(v) on gradients near zero
+    assert (num / den) ** 0.5 <= float(__import__("os").environ.get("GMP_TEST_UPDATE_TOL", "1e-3")), f"relative update error {(num / den) ** 0.5:.3e}"
+    assert abs(proj - mo["gradient_surgery/total_projections"]) <= 24
     # the clip norm the engine used equals the oracle's pre-clip gradient norm
     # (oracle grads are post-clip now; recompute from the engine's unclipped final gradient instead)
     assert eng.normsq.item() > 0
