@@ -68,11 +68,24 @@ from gnn_pretraining_amd.pretrain.control import TemperatureScheduler  # noqa: E
 SCHEME = "s4"
 GRAPHS_PER_STEP = 32
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-# HBM bytes per launch of the aggregation kernel at exactly this rung, from separate rocprofv3 --pmc passes
-# (profiles/r01_pmc_aggregate_stream.csv): FETCH_SIZE 1,352,746 KB x 2 (gfx950 reports half of wide coalesced reads,
-# MI355X_MICROARCH.md section HBM) + WRITE_SIZE 2,146,816 KB, x 1024.  PMC passes cannot run inside this process.
+# HBM bytes per launch of the aggregation kernel at exactly this rung, from separate rocprofv3 --pmc passes (FETCH_SIZE x 2: gfx950
+# reports half of wide coalesced reads, MI355X_MICROARCH.md section HBM; + WRITE_SIZE; x 1024).  PMC passes cannot run inside this
+# process, so the figure is a constant -- tied to the source it was measured on: `roofline.traffic` is reported only while
+# csrc/aggregate.hip still hashes to PMC_SOURCE_SHA16 (and the rung is PMC_SHAPE), null otherwise (re-measure: profiles/README.md).
 PMC_SHAPE = (2146816, 8068480)
-PMC_TRAFFIC_BYTES = int((1229698.6 * 2 + 2147421.6) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv (FETCH_SIZE x2: gfx950 correction)
+PMC_TRAFFIC_BYTES = int((1229698.6 * 2 + 2147421.6) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv
+PMC_SOURCE_SHA16 = "6a8eb86a0b5aea23"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernel (c9bd553 + 38b1a88)
+
+
+def pmc_traffic(shape):
+    import hashlib
+    try:
+        sha = hashlib.sha256(open(os.path.join(ROOT, "gnn_pretraining_amd", "csrc", "aggregate.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+    return PMC_TRAFFIC_BYTES if (shape == PMC_SHAPE and sha == PMC_SOURCE_SHA16) else None
+
+
 PRIME_STEPS = 30                # untimed set-up steps before the caller's warm-up (kernel code objects, workspaces, clocks)
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
 
@@ -147,7 +160,7 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     alg_bytes = 2 * 4 * 256 * N + 4 * (N + 1) + 4 * E
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES if (N, E) == PMC_SHAPE else None, "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic((N, E)), "traffic_source": f"rocprofv3 --pmc passes on aggregate.hip sha256 {PMC_SOURCE_SHA16}", "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters,
             # for orientation only (frac above is against the 8 TB/s spec): the part's measured float4 copy rate, MI355X_MICROARCH.md
             "measured_copy_ceiling": 6290.0, "frac_of_copy_ceiling": round(achieved / 6290.0, 4)}
@@ -184,32 +197,39 @@ def gemm_roofline(device, rows: int = 7392):
 def cpu_baseline(seed: int, budget_s: float = 20.0):
     """The CPU oracle (a port: the reference itself needs torch_geometric) on this box's host cores."""
     from oracle import models as OM, tasks as OTk, train as OTr
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity_util import to_oracle
+    from oracle.harness import to_oracle
     cores = host_cores()
-    torch.set_num_threads(cores)
-    torch.manual_seed(seed)
-    random.seed(seed)                 # PyG's negative sampler (oracle/augment.py) draws from Python's global `random`
-    gen = torch.Generator().manual_seed(seed)
     domains, tasks = PT.PRETRAIN_DOMAINS[SCHEME], PT.ACTIVE_TASKS[SCHEME]
-    model = OM.PretrainableGNN(torch.device("cpu"), domains, tasks)
-    model.train()
-    temp, grl = OTr.TemperatureScheduler(462 * 50), OTr.GRLScheduler(50, 462)
-    otasks = OTk.instantiate_tasks(model, tasks, grl, temp)
-    opt, bal = OTr.make_optimizer(model, tasks), OTr.AdaptiveLossBalancer()
-    pool = [{d: to_oracle(b) for d, b in S.pretrain_step_batches(gen, domains).items()} for _ in range(4)]
-    for i in range(2):
-        OTr.train_step(model, otasks, opt, bal, grl, temp, pool[i % 4], gen)
-    times, t_end = [], time.time() + budget_s
-    while time.time() < t_end and len(times) < 50:
-        t0 = time.time()
-        OTr.train_step(model, otasks, opt, bal, grl, temp, pool[len(times) % 4], gen)
-        times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+
+    def run(threads: int, budget: float, cap: int):
+        torch.set_num_threads(threads)
+        torch.manual_seed(seed)
+        random.seed(seed)             # PyG's negative sampler (oracle/augment.py) draws from Python's global `random`
+        gen = torch.Generator().manual_seed(seed)
+        model = OM.PretrainableGNN(torch.device("cpu"), domains, tasks)
+        model.train()
+        temp, grl = OTr.TemperatureScheduler(462 * 50), OTr.GRLScheduler(50, 462)
+        otasks = OTk.instantiate_tasks(model, tasks, grl, temp)
+        opt, bal = OTr.make_optimizer(model, tasks), OTr.AdaptiveLossBalancer()
+        pool = [{d: to_oracle(b) for d, b in S.pretrain_step_batches(gen, domains, enzymes_shaped=True).items()} for _ in range(4)]
+        for i in range(2):
+            OTr.train_step(model, otasks, opt, bal, grl, temp, pool[i % 4], gen)
+        times, t_end = [], time.time() + budget
+        while time.time() < t_end and len(times) < cap:
+            t0 = time.time()
+            OTr.train_step(model, otasks, opt, bal, grl, temp, pool[len(times) % 4], gen)
+            times.append(time.time() - t0)
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    med, n = run(cores, budget_s, 50)
+    med1, n1 = run(1, budget_s / 2, 12)                  # SURVEY section 8d: "also a 1-thread figure"
+    torch.set_num_threads(1)
     return {"value": round(GRAPHS_PER_STEP / med, 2), "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} s4 steps of 32 synthetic ENZYMES-shaped graphs (median {med * 1e3:.1f} ms/step), "
-                      f"torch-only oracle, torch.set_num_threads({cores})"}
+            "sample": f"{n} s4 steps of 32 synthetic ENZYMES-shaped graphs (median {med * 1e3:.1f} ms/step), "
+                      f"torch-only oracle, torch.set_num_threads({cores})",
+            "one_thread": {"value": round(GRAPHS_PER_STEP / med1, 2), "cores": 1,
+                           "sample": f"{n1} steps of the same workload (median {med1 * 1e3:.1f} ms/step), torch.set_num_threads(1)"}}
 
 
 def main() -> None:

@@ -122,7 +122,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_mt_pcgrad_clip_adamw": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
                                            f32, p, p, p, p, p, sz, i32, p]),
     "gmp_mt_pcgrad_clip_adamw_ex": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
-                                              f32, p, p, p, p, p, sz, i32, i32, i32, i32, p]),
+                                              f32, p, p, p, p, p, sz, i32, i32, i32, i32, p, p]),
 }
 
 

@@ -549,7 +549,6 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     g.groups = groups;
     g.gsplit = 1;
     g.vecC = (ldc % 4 == 0) && aligned16(C);
-    take_signal(g);
     g.asum = mode == GMP_GEMM_TN ? a_colsum : nullptr;
     int64_t max_rows = 0;
     for (int i = 0; i <= groups; ++i) {
@@ -569,7 +568,8 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
     if (mode == GMP_GEMM_TN) {
         g.M = M_tn;          // output rows = columns of A (k-major A: lda >= M_tn); the reduction runs over the group's rows
         g.K = 0;
-        if (g.M == 0) return GMP_OK;
+        if (g.M == 0) return GMP_OK;          // (nothing launched: a pending signal stays pending, the caller opens the gate itself)
+        take_signal(g);
         // long reductions (the per-task weight gradients of the stacked backward): the pipelined kernel; tile and the number of
         // row slices per group are chosen together for the shortest grid (rounds of 256 CUs x K-steps per block x MFMAs per step)
         // (only for callers that hand over a workspace, i.e. opted into row slices: the grouped NT-Xent does not, and stays
@@ -626,6 +626,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         }
     } else {
         if (max_rows == 0) return GMP_OK;
+        take_signal(g);
         g.M = 0;
         static const bool nofast_g2 = getenv("GMP_GEMM_NOFAST") != nullptr;
         g.K = K;

@@ -48,6 +48,7 @@ struct MtArgs {
     const float* lr;           // [K]
     const float* wd;           // [K]
     float beta1, beta2, eps, max_norm;
+    const int* abort;          // nullable: nonzero at run time = something upstream went wrong (a cross-stream gate timed out): no update
 };
 
 __global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
             flag = 1;
         }
         a.flags[k] = flag;
-        if (a.steps) a.steps[k] += (float)flag;     // torch.optim keeps a per-parameter step that only advances with a gradient
+        if (a.steps && !(a.abort && *a.abort)) a.steps[k] += (float)flag;     // torch.optim keeps a per-parameter step that only advances with a gradient
     }
     s_conf[threadIdx.x] = conf;
     s_proj[threadIdx.x] = proj;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
 __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
     const int k = blockIdx.x, j = blockIdx.y;
     if (!a.flags[k]) return;                                   // grad is None: torch skips the parameter entirely
+    if (a.abort && *a.abort) return;                           // the step's inputs are not to be trusted: leave parameters and moments alone
     // clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); max_norm <= 0 disables clipping
     float coef = 1.f;
     if (a.max_norm > 0.f) coef = fminf(1.f, a.max_norm / (sqrtf(a.normsq[0]) + 1e-6f));
@@ -342,7 +344,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task
                                            const float* lr, const float* wd, float beta1, float beta2, float eps,
                                            float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
                                            int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
-                                           int k_begin, int k_end, int phases, gmp_stream_t stream) {
+                                           int k_begin, int k_end, int phases, const int32_t* abort_flag, gmp_stream_t stream) {
     if (k_begin < 0 || k_end > num_tensors || k_begin > k_end || !(phases & 3))
         return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tensors [%d, %d) of %d, phases %d", k_begin, k_end, num_tensors, phases);
     if (num_tasks < 1 || num_tasks > MAXT || num_tensors < 1 || n_order < 1 || n_order > num_tasks)
@@ -370,6 +372,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task
     a.n_order = n_order; a.last_task = last_task; a.extra_task = extra_task;
     a.final_grad = final_grad; a.normsq = normsq_out; a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
     a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    a.abort = abort_flag;
     hipStream_t st = (hipStream_t)stream;
     const int nk = k_end - k_begin;
     if ((phases & 1) && nk > 0) {
@@ -397,5 +400,5 @@ extern "C" int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_st
                                         gmp_stream_t stream) {
     return gmp_mt_pcgrad_clip_adamw_ex(task_grads, task_stride, num_tasks, num_tensors, tensor_off, tensor_len, has, order_host, n_order,
                                        last_task, extra_task, params, exp_avg, exp_avg_sq, steps, lr, wd, beta1, beta2, eps, max_norm,
-                                       final_grad, normsq_out, metrics_out, flags_out, ws, ws_bytes, apply_update, 0, num_tensors, 3, stream);
+                                       final_grad, normsq_out, metrics_out, flags_out, ws, ws_bytes, apply_update, 0, num_tensors, 3, nullptr, stream);
 }

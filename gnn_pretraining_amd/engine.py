@@ -1243,7 +1243,9 @@ class StepEngine:
                 oidx, len(idx), names.index(main_tasks[-1]), extra, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, self.max_grad_norm,
                 self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(), self.mt_ws.data_ptr(),
-                self.mt_ws.numel(), int(apply_update), k0, k1, phases, stream), "mt_pcgrad_clip_adamw")
+                self.mt_ws.numel(), int(apply_update), k0, k1, phases,
+                (self.sync_flags.data_ptr() + 4 * 63) if self.use_gates else None,      # a timed-out gate: no update from this step on
+                stream), "mt_pcgrad_clip_adamw")
 
         if self.parts_beside_backward:
             # PCGrad follows the backward part by part on the exchange stream (Gram / solve / combine of a part as soon as its

@@ -426,7 +426,10 @@ int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, in
                                 const float* lr, const float* wd, float beta1, float beta2, float eps,
                                 float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
                                 int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
-                                int k_begin, int k_end, int phases, gmp_stream_t stream);
+                                int k_begin, int k_end, int phases, const int32_t* abort_flag, gmp_stream_t stream);
+/* abort_flag (nullable, device): when *abort_flag != 0 at run time neither parameters, moments nor step counters are touched -- the
+ * engine passes the error word of its cross-stream gates (sync_flags[63]), so a gate that timed out cannot turn into an update
+ * computed from incomplete gradients; the host sees the flag at its next check_gates(). */
 
 
 #ifdef __cplusplus

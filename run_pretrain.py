@@ -49,8 +49,23 @@ def main() -> None:
         jobs = list(product(SCHEMES, SEEDS))
         n = num_gpus()
         print(f"Starting pretraining sweep: {len(jobs)} experiments on {n} GPU(s)")
+        # one job per GPU at a time: a worker takes a free GPU id from the queue and gives it back when its job ends (pinning job i
+        # to GPU i % n let a GPU whose job finished early sit idle while two jobs shared another -- and two engines on one GPU also
+        # skew the engine's stream / hardware-queue calibration)
+        import queue
+        free = queue.Queue()
+        for g in range(n):
+            free.put(g)
+
+        def run_on_free_gpu(job):
+            g = free.get()
+            try:
+                return run_one((job[0], job[1], extra, g))
+            finally:
+                free.put(g)
+
         with ThreadPoolExecutor(max_workers=n) as ex:
-            results = list(ex.map(run_one, [(e, s, extra, i % n) for i, (e, s) in enumerate(jobs)]))
+            results = list(ex.map(run_on_free_gpu, jobs))
         failed = [r for r in results if not r[0]]
         print(f"ok {len(results) - len(failed)}  failed {len(failed)}")
         for _, e, s, msg in failed:

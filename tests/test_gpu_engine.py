@@ -43,39 +43,7 @@ def build(scheme, seed, rng_mode="reference", make_host=None, **engine_kw):
     return om, hm, eng, host, inp, gen, tasks, domains
 
 
-def view_to_oracle(host_batch, v):
-    """ViewArrays -> the oracle's Batch of augmented graphs (features gathered and attribute-masked on the host)."""
-    from oracle import graph_ops as OG
-    rows = torch.from_numpy(np.asarray(v.rows, dtype=np.int64))
-    x = host_batch.x[rows].clone()
-    if v.rowmask is not None:
-        F = x.size(1)
-        bits = ((v.rowmask[:, None] >> np.arange(F, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
-        x[torch.from_numpy(bits)] = 0.0
-    ptr = torch.from_numpy(np.asarray(v.ptr, dtype=np.int64))
-    batch = torch.repeat_interleave(torch.arange(len(ptr) - 1), ptr[1:] - ptr[:-1])
-    ei = torch.from_numpy(np.asarray(v.edges, dtype=np.int64))
-    eptr = torch.zeros(len(ptr), dtype=torch.long)      # not used by the oracle losses
-    return OG.Batch(x, ei, batch, ptr, eptr, host_batch.y, host_batch.graph_properties)
-
-
-def oracle_artefacts(art, host):
-    out = {}
-    for t, a in art.items():
-        if t in ("node_contrast", "graph_contrast"):
-            conv = {}
-            for d, views in a.items():
-                if views is None:
-                    conv[d] = None
-                    continue
-                b1, b2 = view_to_oracle(host[d], views[0]), view_to_oracle(host[d], views[1])
-                c1 = torch.zeros(b1.num_nodes, dtype=torch.bool); c1[torch.from_numpy(views[0].common)] = True
-                c2 = torch.zeros(b2.num_nodes, dtype=torch.bool); c2[torch.from_numpy(views[1].common)] = True
-                conv[d] = OTk.TwoViews(b1, b2, c1, c2)
-            out[t] = conv
-        else:
-            out[t] = {d: torch.from_numpy(np.asarray(v, dtype=np.int64)) for d, v in a.items()}
-    return out
+from oracle.harness import oracle_artefacts, view_to_oracle                      # noqa: E402,F401
 
 
 @pytest.mark.parametrize("scheme,seed,rng_mode", [("s4", 41, "reference"), ("b2", 42, "reference"), ("s2", 43, "reference"),
@@ -502,3 +470,25 @@ def test_engine_validation_consumes_the_generator_like_the_reference_loop(tmp_pa
     assert set(m_mod) == set(m_eng)
     for k, v in m_mod.items():
         assert abs(m_eng[k] - v) <= 2e-4 * max(abs(v), 1e-3), (k, m_eng[k], v)
+
+
+def test_a_raised_gate_error_flag_blocks_the_update():
+    """A cross-stream gate that times out sets sync_flags[63] and lets its stream run on incomplete data.  The optimizer reads that
+    word on the device (gmp_mt_pcgrad_clip_adamw_ex abort_flag): from then on no step changes parameters, moments or step counters,
+    and the host learns of it at its next check (losses() / check_gates())."""
+    _, hm, eng, host, inp, gen, tasks, _ = build("s4", 91)
+    if not eng.use_gates:
+        pytest.skip("no hardware queue per stream on this box: events carry the dependencies, there is no gate to time out")
+    eng.step(inp, gen, order=list(tasks))
+    torch.cuda.synchronize()
+    p0, m0, s0 = eng.flat.clone(), eng.exp_avg.clone(), eng.steps.clone()
+    eng.sync_flags[63] = 1
+    eng.step(inp, gen, order=list(tasks))
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat, p0) and torch.equal(eng.exp_avg, m0) and torch.equal(eng.steps, s0)
+    with pytest.raises(Exception, match="gate timed out"):
+        eng.losses()
+    eng.sync_flags[63] = 0
+    eng.step(inp, gen, order=list(tasks))
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.flat, p0)
