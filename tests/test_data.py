@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from gnn_pretraining_amd import synthetic
+from gnn_pretraining_amd import synthetic as S
 from gnn_pretraining_amd.data import data_setup as DS
 from gnn_pretraining_amd.data.finetune_data_loaders import create_finetune_data_loader
 from gnn_pretraining_amd.data.graph_properties import GraphPropertyCalculator, standardize
@@ -227,3 +228,81 @@ def test_finetune_loaders(processed):
     lab = torch.cat([l for _, _, l in vl])
     assert lab.numel() == len(vl.dataset) and lab.sum() * 2 == lab.numel()               # positives then negatives
     assert lab[: lab.numel() // 2].min() == 1 and lab[lab.numel() // 2:].max() == 0
+
+
+# ---- the bridge from the reference's on-disk contract (data_setup.py:66-72) ------------------------------------------------
+class _PygLikeData:
+    """What the reference pickles: an object with x, edge_index (graph-local ids), y and num_nodes -- the attribute names of
+    torch_geometric.data.Data, none of this repository's classes."""
+
+    def __init__(self, x, edge_index, y):
+        self.x, self.edge_index, self.y = x, edge_index, y
+
+    @property
+    def num_nodes(self):
+        return self.x.size(0)
+
+
+def test_export_bridge_tudataset_shaped(tmp_path):
+    from gnn_pretraining_amd.data.export import export_dataset
+    gen = _gen(21)
+    graphs = [S.random_graph(gen, 7, 18.0, 20.0, num_classes=2) for _ in range(48)]
+    pyg_like = [_PygLikeData(g.x.double(), g.edge_index.clone(), g.y) for g in graphs]          # (float64 x: cast on export)
+    splits = {"train": torch.arange(0, 38), "val": torch.arange(38, 48)}
+    props = torch.randn(48, 12, generator=gen)
+    export_dataset(pyg_like, splits, props, tmp_path / "MUTAG")
+    store = GraphStore.load(tmp_path / "MUTAG")
+    assert len(store) == 48 and store.x.dtype == torch.float32 and torch.equal(store.graph_properties, props)
+    pick = [3, 17, 3, 39]
+    ref = [Data(graphs[i].x, graphs[i].edge_index, graphs[i].y, props[i]) for i in pick]
+    _same_batch(store.collate(pick), Batch.from_data_list(ref))
+    assert torch.equal(load_splits(tmp_path / "MUTAG")["val"], splits["val"])
+    # ... and the loaders run on the exported tree, drawing as the reference's sampler does (pretrain_data_loaders.py:35-43)
+    loader = create_train_data_loader(["MUTAG"], _gen(0), tmp_path)
+    want = torch.randint(0, 38, (32,), generator=_gen(0))
+    _same_batch(next(iter(loader))["MUTAG"], store.collate(splits["train"][want]))
+    assert sum(b.num_graphs for b in create_val_data_loader("MUTAG", _gen(0), tmp_path)) == 10
+
+
+def test_export_bridge_planetoid_shaped(tmp_path):
+    """Cora_NC / Cora_LP: ONE Data with node labels; splits are node-id vectors, or [2, k] edge lists (data_setup.py:116-160)."""
+    from gnn_pretraining_amd.data.export import export_dataset
+    gen = _gen(22)
+    n, f = 120, 33
+    ei = torch.randint(0, n, (2, 400), generator=gen)
+    x = torch.rand(n, f, generator=gen)
+    g = _PygLikeData(x, ei, torch.randint(0, 7, (n,), generator=gen))
+    nc = {"train": torch.arange(0, 20), "val": torch.arange(20, 50), "test": torch.arange(50, 120)}
+    export_dataset([g], nc, None, tmp_path / "Cora_NC")
+    st = GraphStore.load(tmp_path / "Cora_NC")
+    assert len(st) == 1 and st.node_level_labels and torch.equal(st.graph(0).y, g.y) and torch.equal(st.graph(0).edge_index, ei)
+    lp = {"train_pos": ei[:, :300], "val_pos": ei[:, 300:350], "val_neg": ei[:, 350:400].flip(0), "test_pos": ei[:, 350:], "test_neg": ei[:, :50].flip(0)}
+    export_dataset([g], lp, None, tmp_path / "Cora_LP")
+    got = load_splits(tmp_path / "Cora_LP")
+    assert set(got) == set(lp) and all(torch.equal(got[k], lp[k]) for k in lp)
+
+
+def test_export_bridge_refuses_global_edge_ids(tmp_path):
+    from gnn_pretraining_amd.data.export import export_dataset
+    g = _PygLikeData(torch.zeros(3, 2), torch.tensor([[0, 5], [1, 2]]), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(ValueError, match="local"):
+        export_dataset([g], {"train": torch.arange(1)}, None, tmp_path / "X")
+
+
+def test_export_tree_walks_the_reference_layout(tmp_path):
+    """data/processed/{D}/{data,splits,graph_properties}.pt -> {D}/*.safetensors, with the .pt files written by torch.save the way
+    data_setup.save_processed_data does (here: our own picklable stand-ins, loaded with the default loader)."""
+    from gnn_pretraining_amd.data.export import export_processed_tree
+    gen = _gen(23)
+    src = tmp_path / "processed"
+    for name, dim in (("ENZYMES", 21), ("NCI1", 37)):
+        graphs = [S.random_graph(gen, dim) for _ in range(12)]
+        (src / name).mkdir(parents=True)
+        torch.save(graphs, src / name / "data.pt")
+        torch.save({"train": torch.arange(0, 9), "val": torch.arange(9, 12)}, src / name / "splits.pt")
+        torch.save(torch.randn(12, 12, generator=gen), src / name / "graph_properties.pt")
+    out = export_processed_tree(src, tmp_path / "export")
+    assert sorted(out) == ["ENZYMES", "NCI1"]
+    for name in out:
+        st = GraphStore.load(tmp_path / "export" / name)
+        assert len(st) == 12 and st.graph_properties.shape == (12, 12)
