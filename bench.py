@@ -86,6 +86,7 @@ def pmc_traffic(shape):
     return PMC_TRAFFIC_BYTES if (shape == PMC_SHAPE and sha == PMC_SOURCE_SHA16) else None
 
 
+ROOFLINE_BWD = None
 PRIME_STEPS = 30                # untimed set-up steps before the caller's warm-up (kernel code objects, workspaces, clocks)
 POOL = 8                       # distinct pre-generated step inputs, resident in HBM before the timed region
 
@@ -159,6 +160,32 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(iters)) / iters
     alg_bytes = 2 * 4 * 256 * N + 4 * (N + 1) + 4 * E
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    # the backward of the same rung (gmp_gin_aggregate_bwd: g_x = (1 + eps) g + sum over the TRANSPOSED CSR of g, and the eps
+    # gradient sum_r <g[r], x[r]>): the same LDS-resident-tile kernel on the by-source CSR, with the layer input x streamed beside
+    # it for the row products.  Algorithmic bytes: read g, read x, write g_x (3 x 1 KiB per row) + the transposed index arrays +
+    # the row products written and read back once by the two-stage sum
+    g = torch.randn(N, 256, device=device)
+    gx, geps = torch.empty_like(x), torch.empty(1, device=device)
+    ws = torch.empty(l.gmp_gin_aggregate_bwd_workspace_bytes(N, 256), dtype=torch.uint8, device=device)
+    bargs = (ops._ptr(g), ops._ptr(csr.rowptr_t), ops._ptr(csr.col_t), ops._ptr(eps), ops._ptr(x), ops._ptr(gx), ops._ptr(geps), N, 256,
+             ops._ptr(ws), ws.numel())
+    for _ in range(5):
+        ops.L.check(l.gmp_gin_aggregate_bwd(*bargs, ops._stream(x)), "aggregate bwd")
+    torch.cuda.synchronize(device)
+    evb = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    evb[0].record()
+    for i in range(iters):
+        ops.L.check(l.gmp_gin_aggregate_bwd(*bargs, ops._stream(x)), "aggregate bwd")
+        evb[i + 1].record()
+    torch.cuda.synchronize(device)
+    ms_b = sum(evb[i].elapsed_time(evb[i + 1]) for i in range(iters)) / iters
+    bytes_b = 3 * 4 * 256 * N + 4 * (N + 1) + 4 * E + 2 * 4 * N
+    ach_b = bytes_b / (ms_b * 1e-3) / 1e9
+    global ROOFLINE_BWD
+    ROOFLINE_BWD = {"bound": "hbm", "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                    "traffic": None, "kernel": "gin_aggregate_ldstile_kernel<DOT> + 2 small sum kernels (gmp_gin_aggregate_bwd with the eps "
+                                               "gradient, N >= 65536)", "rows": N, "edges": E, "bytes_per_launch": bytes_b,
+                    "avg_launch_ms": round(ms_b, 4), "launches": iters, "frac_of_copy_ceiling": round(ach_b / 6290.0, 4)}
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic((N, E)), "traffic_source": f"rocprofv3 --pmc passes on aggregate.hip sha256 {PMC_SOURCE_SHA16}", "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters,
@@ -252,7 +279,7 @@ def main() -> None:
 
     if a.roofline_only:
         torch.cuda.set_device(0)
-        emit({"roofline": aggregation_roofline(torch.device("cuda:0"))})
+        emit({"roofline": aggregation_roofline(torch.device("cuda:0")), "roofline_bwd": ROOFLINE_BWD})
         return
     from gnn_pretraining_amd._host import limit_host_threads
     limit_host_threads(1)      # the host side of a step is tiny index work: torch's default pool (every core of the node, per rank) only hurts
@@ -353,7 +380,7 @@ def main() -> None:
                        "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                        "devices_visible": torch.cuda.device_count(),
                        "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
-            "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm,
+            "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm, "roofline_bwd": ROOFLINE_BWD,
         }
         emit(line)
     if world > 1:

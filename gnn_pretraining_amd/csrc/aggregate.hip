@@ -187,10 +187,16 @@ __global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* 
 // leave a graph) are read from LDS; only the graphs cut by a tile border reach into global memory.  The next tile's
 // rows / rowptr / col are prefetched into registers while the current tile is being reduced, so HBM stays busy during
 // the LDS phase; the output leaves with non-temporal stores.
-template <int SB, int TILE, int CCAP, bool NT_STORE>
+// DOT (the backward with the eps gradient, gmp_gin_aggregate_bwd: x = upstream gradient on the TRANSPOSED CSR, dotx = the layer's
+// forward input): also rowdot[r] = <x[r], dotx[r]>.  The rows a wave reduces are exactly the rows whose float4 its threads would
+// hold of a tile laid out thread-linear (thread i <-> row i / 64 = wave + 16 k), so the dotx tile never goes through LDS: each
+// thread loads its own nine float4 of it when the tile is entered -- in flight beside the next tile's prefetch while the first
+// rows are reduced -- and multiplies them with the row it is reducing anyway.  One extra KiB per row read, nothing re-read.
+template <int SB, int TILE, int CCAP, bool NT_STORE, bool DOT = false>
 __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
                                                                    const int* __restrict__ col, const float* __restrict__ eps,
-                                                                   float4* __restrict__ out, int64_t nrows, int tiles_per_block) {
+                                                                   float4* __restrict__ out, int64_t nrows, int tiles_per_block,
+                                                                   const float4* __restrict__ dotx = nullptr, float* __restrict__ rowdot = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_x = reinterpret_cast<float4*>(smem);
     int* s_col = reinterpret_cast<int*>(smem + (size_t)TILE * 1024);
@@ -252,13 +258,27 @@ __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4*
             }
         }
         __syncthreads();
+        // this tile's rows of dotx, thread-linear: qx[k] belongs to row wv + k * SWAVES.  Requested AHEAD rows before their use (a row
+        // of the reduction lasts about one HBM latency at the target rate), not all at once: nine live float4 beside the next tile's
+        // nine spilled 30 registers of the 128 a 1024-thread block may hold
+        constexpr int AHEAD = 3;
+        float4 qx[DOT ? XPT : 1];
+        auto load_q = [&](int k) -> float4 {
+            const int i = threadIdx.x + k * SB;
+            return i < nr * 64 ? dotx[r0 * 64 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (DOT) {
+#pragma unroll
+            for (int k = 0; k < AHEAD && k < XPT; ++k) qx[k] = load_q(k);
+        }
         if (t + 1 < tend) GMP_PREFETCH_TILE(t + 1, eB, eC);   // in flight while this tile is reduced out of LDS
         const int r0i = (int)r0;
         auto row_of = [&](int u) -> float4 {
             const unsigned loc = (unsigned)(u - r0i);
             return loc < (unsigned)nr ? s_x[loc * 64 + lane] : x[(int64_t)u * 64 + lane];
         };
-        for (int rr = wv; rr < nr; rr += SWAVES) {
+        static_assert(!DOT || SB / GMP_WAVE * XPT >= TILE, "DOT: every row of the tile has a register slot");
+        auto reduce_row = [&](int rr) {
             const int start = s_ptr[rr], end = s_ptr[rr + 1];
             float4 acc = s_x[rr * 64 + lane];
             acc = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
@@ -284,6 +304,20 @@ __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4*
             } else {
                 out[(r0 + rr) * 64 + lane] = acc;
             }
+        };
+        if (DOT) {            // unrolled: the register slot of a row's dotx piece is a compile-time index
+#pragma unroll
+            for (int kq = 0; kq < XPT; ++kq) {
+                const int rr = wv + kq * SWAVES;
+                if (rr >= nr) break;
+                if (kq + AHEAD < XPT) qx[kq + AHEAD] = load_q(kq + AHEAD);
+                const float4 g = s_x[rr * 64 + lane];
+                const float d = gmp::wave_sum((g.x * qx[kq].x + g.y * qx[kq].y) + (g.z * qx[kq].z + g.w * qx[kq].w));
+                if (lane == 0) rowdot[r0 + rr] = d;
+                reduce_row(rr);
+            }
+        } else {
+            for (int rr = wv; rr < nr; rr += SWAVES) reduce_row(rr);
         }
         eB = eC;
         eC = eD;
@@ -356,6 +390,42 @@ int launch_nv(int nv, const Plan& p, hipStream_t st, const float* src, const int
     return gmp::check_launch("seg_sum_kernel");
 }
 
+// the default streaming form (144-row tiles = 153 KB of the CU's 160 KB LDS, 1024 threads, one block per CU), forward or -- on the
+// transposed CSR, with the optional <g, x> row products for the eps gradient -- backward
+template <bool DOT>
+int launch_ldstile144(const float* x, const int* rowptr, const int* col, const float* eps, float* out, int64_t N, const float* dotx,
+                      float* rowdot, hipStream_t st) {
+    constexpr int SBV = 1024, TILEV = 144, CCAPV = 2048;
+    auto kern = gin_aggregate_ldstile_kernel<SBV, TILEV, CCAPV, true, DOT>;
+    const size_t lds = (size_t)TILEV * 1024 + (size_t)CCAPV * 4 + (size_t)(TILEV + 16) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_ldstile: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int64_t ntiles = (N + TILEV - 1) / TILEV;
+    const int blocks = 256;
+    const int tpb = (int)((ntiles + blocks - 1) / blocks);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(SBV), lds, st, (const float4*)x, rowptr, col, eps, (float4*)out, N, tpb,
+                       (const float4*)dotx, rowdot);
+    return gmp::check_launch("gin_aggregate_ldstile_kernel");
+}
+
+// sum of n floats in a fixed order: `nb` block partials (grid-stride by block, tree inside), then reduce_partials_kernel over them
+__global__ __launch_bounds__(256) void block_partials_kernel(const float* __restrict__ p, int64_t n, float* __restrict__ part) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
 int check_feat(const char* who, int feat) {
     if (feat <= 0 || feat % 4 != 0 || feat > 1024)
         return gmp::fail(GMP_ERR_ARG, "%s: feature width %d must be a multiple of 4 in [4,1024]", who, feat);
@@ -401,12 +471,13 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
             int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \
             int tpb = (int)((ntiles + blocks - 1) / blocks);                                                          \
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(SBV), lds, st, (const float4*)x, rowptr, col, eps,            \
-                               (float4*)out, N, tpb);                                                                 \
+                               (float4*)out, N, tpb, (const float4*)nullptr, (float*)nullptr);                        \
         } while (0)
         switch (variant) {
             case 5: GMP_LDSTILE(1024, 128, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 6: GMP_LDSTILE(512, 64, 1024, true, 512); return gmp::check_launch("gin_aggregate_ldstile_kernel");
-            case 12: GMP_LDSTILE(1024, 144, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
+            case 12: if (blocks_env <= 0) return launch_ldstile144<false>(x, rowptr, col, eps, out, N, nullptr, nullptr, st);
+                     GMP_LDSTILE(1024, 144, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 8: GMP_LDSTILE(1024, 128, 2048, false, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
             case 1: GMP_STREAM(1024, 256, false, 512); break;
             case 2: GMP_STREAM(1024, 512, true, 512); break;
@@ -425,7 +496,7 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
 
 extern "C" size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t N, int feat) {
     (void)feat;
-    return (size_t)(N > 0 ? N : 1) * sizeof(float) + 256;   // one <g, x> per row, summed in a second pass
+    return (size_t)(N > 0 ? N : 1) * sizeof(float) + 256 + 1024 * sizeof(float);   // one <g, x> per row (+ block partials), summed in a second pass
 }
 
 extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t,
@@ -440,6 +511,18 @@ extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t
     if (N == 0) {
         if (g_eps && hipMemsetAsync(g_eps, 0, sizeof(float), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_bwd: memset");
         return GMP_OK;
+    }
+    // beyond the caches (the roofline rung): the forward's LDS-resident-tile kernel on the transposed CSR (GMP_AGG_BWD_TILE=0: off)
+    static const bool tile_bwd = !(getenv("GMP_AGG_BWD_TILE") && atoi(getenv("GMP_AGG_BWD_TILE")) == 0);
+    if (feat == 256 && N >= 65536 && tile_bwd && col_t) {
+        if (!g_eps) return launch_ldstile144<false>(g_out, rowptr_t, col_t, eps, g_x, N, nullptr, nullptr, st);
+        if (ws_bytes < gmp_gin_aggregate_bwd_workspace_bytes(N, feat)) return gmp::fail(GMP_ERR_WORKSPACE, "gin_aggregate_bwd: workspace");
+        float* rowdot = (float*)ws;
+        float* part = rowdot + ((N + 63) / 64) * 64;
+        if (int rc = launch_ldstile144<true>(g_out, rowptr_t, col_t, eps, g_x, N, x, rowdot, st)) return rc;
+        hipLaunchKernelGGL(block_partials_kernel, dim3(1024), dim3(256), 0, st, (const float*)rowdot, N, part);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)part, 1024, g_eps);
+        return gmp::check_launch("gin_aggregate_bwd reduce");
     }
     Plan p = make_plan(N);
     if (!g_eps)

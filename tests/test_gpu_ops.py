@@ -86,6 +86,29 @@ def test_gin_aggregate_fwd_bwd(graphs, F):
     close(ge, er.grad, what="aggregate g_eps", scale=(g * x).abs().sum().item() / (n * F) ** 0.5)
 
 
+@pytest.mark.parametrize("with_eps_grad", [True, False])
+def test_gin_aggregate_streaming_backward(with_eps_grad):
+    """N >= 65,536 rows: the backward takes the LDS-resident-tile kernel on the transposed CSR (the roofline rung's `roofline_bwd`),
+    with the row products <g, x> of the eps gradient riding along.  Against autograd through the oracle's aggregation: ENZYMES-
+    shaped graphs (~69 k rows), and a random graph whose neighbours mostly lie outside the LDS tile, with isolated rows."""
+    gen = torch.Generator().manual_seed(78)
+    b = S.domain_batch(gen, 4, 2100)
+    for ei, n in ((b.edge_index, b.num_nodes), (None, 516 * 128)):
+        if ei is None:
+            ei = torch.randint(0, n, (2, 300_000), generator=gen)
+            ei = ei[:, (ei[0] % 5) != 0]                        # every 5th row sends nothing: empty rows of the transposed CSR
+        assert n >= 65536
+        x = torch.randn(n, 256, generator=gen).requires_grad_(True)
+        eps = torch.tensor([0.3], requires_grad=True)
+        g = torch.randn(n, 256, generator=gen)
+        OG.gin_aggregate(x, ei, eps).backward(g)
+        csr = ops.csr_build(ei.to(DEV), n)
+        gx, geps = ops.gin_aggregate_bwd(g.to(DEV), csr.rowptr_t, csr.col_t, eps.detach().to(DEV), x.detach().to(DEV) if with_eps_grad else None)
+        close(gx, x.grad, what="streaming aggregate backward: g_x")
+        if with_eps_grad:
+            close(geps, eps.grad, rtol=2e-4, what="streaming aggregate backward: g_eps (one sum of n * 256 products)")
+
+
 def test_gin_aggregate_streaming_kernel():
     """N >= 65,536 rows takes the LDS-resident-tile kernel (the roofline rung's path); a dense random graph
     forces its un-staged fallback (more neighbour ids per 128-row tile than the LDS stage holds)."""
