@@ -73,17 +73,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # process, so the figure is a constant -- tied to the source it was measured on: `roofline.traffic` is reported only while
 # csrc/aggregate.hip still hashes to PMC_SOURCE_SHA16 (and the rung is PMC_SHAPE), null otherwise (re-measure: profiles/README.md).
 PMC_SHAPE = (2146816, 8068480)
-PMC_TRAFFIC_BYTES = int((1229698.6 * 2 + 2147421.6) * 1024)     # profiles/r01_pmc_aggregate_ldstile.csv
-PMC_SOURCE_SHA16 = "6a8eb86a0b5aea23"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernel (c9bd553 + 38b1a88)
+PMC_TRAFFIC_BYTES = int((1229841.7 * 2 + 2146902.4) * 1024)     # profiles/r02_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
+PMC_TRAFFIC_BYTES_BWD = int((2689442.0 * 2 + 2167694.2) * 1024) # same file, backward with the eps row products (1.16 x algorithmic)
+PMC_SOURCE_SHA16 = "094d745b096dd17c"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernels
 
 
-def pmc_traffic(shape):
+def pmc_traffic(shape, backward: bool = False):
     import hashlib
     try:
         sha = hashlib.sha256(open(os.path.join(ROOT, "gnn_pretraining_amd", "csrc", "aggregate.hip"), "rb").read()).hexdigest()[:16]
     except OSError:
         return None
-    return PMC_TRAFFIC_BYTES if (shape == PMC_SHAPE and sha == PMC_SOURCE_SHA16) else None
+    return (PMC_TRAFFIC_BYTES_BWD if backward else PMC_TRAFFIC_BYTES) if (shape == PMC_SHAPE and sha == PMC_SOURCE_SHA16) else None
 
 
 ROOFLINE_BWD = None
@@ -183,7 +184,7 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
     ach_b = bytes_b / (ms_b * 1e-3) / 1e9
     global ROOFLINE_BWD
     ROOFLINE_BWD = {"bound": "hbm", "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
-                    "traffic": None, "kernel": "gin_aggregate_ldstile_kernel<DOT> + 2 small sum kernels (gmp_gin_aggregate_bwd with the eps "
+                    "traffic": pmc_traffic((N, E), backward=True), "kernel": "gin_aggregate_ldstile_kernel<DOT> + 2 small sum kernels (gmp_gin_aggregate_bwd with the eps "
                                                "gradient, N >= 65536)", "rows": N, "edges": E, "bytes_per_launch": bytes_b,
                     "avg_launch_ms": round(ms_b, 4), "launches": iters, "frac_of_copy_ceiling": round(ach_b / 6290.0, 4)}
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
