@@ -108,6 +108,9 @@ _SIGS: Dict[str, tuple] = {
     "gmp_gate_wait": (C.c_int, [p, C.c_uint64, i32, p, p]),
     "gmp_gate_open": (C.c_int, [p, i32, p]),
     "gmp_gate_set_timeout": (C.c_int, [C.c_double]),
+    "gmp_aug_workspace_bytes": (sz, [i64, i64, i32]),
+    "gmp_aug_node_masks": (C.c_int, [p, p, i32, i64, C.c_uint64, C.c_uint32, p, p]),
+    "gmp_aug_two_views": (C.c_int, [p, p, p, i64, i64, p, i32, i64, i64, i32, C.c_uint64, C.c_uint32, p, p, p, p, p, p, i64, p, p, p, p, p, sz, p]),
     "gmp_upload": (C.c_int, [i32, p, p, p, p]),
     "gmp_segments_pack": (C.c_int, [p, p, p, i32, i64, p]),
     "gmp_segments_unpack": (C.c_int, [p, p, p, i32, i64, f32, p]),

@@ -113,6 +113,18 @@ class ViewArrays:
         self.rows, self.edges, self.ptr, self.rowmask, self.common = rows, edges, ptr, rowmask, common
 
 
+def device_views_to_host(dv) -> Tuple["ViewArrays", "ViewArrays"]:
+    """ops.DeviceViews (gmp_aug_two_views outputs, on the device) -> the two ViewArrays the planner takes.  One small read-back:
+    the counts say how much of the edge / common arrays is valid."""
+    tot = dv.totals.cpu().tolist()
+    out = []
+    for v in range(2):
+        rm = dv.rowmask[v].cpu().numpy().view(np.uint64) if tot[3 + v] else None
+        out.append(ViewArrays(dv.rows[v].cpu().numpy(), dv.edges[v][:, :tot[v]].cpu().numpy(), np.asarray(dv.view_ptr, dtype=np.int64),
+                              rm, dv.common[v][:tot[2]].cpu().numpy()))
+    return out[0], out[1]
+
+
 _HOSTDRAW, _HOSTDRAW_TRIED = None, False
 
 

@@ -449,3 +449,68 @@ def row_fill_(dst: Tensor, idx: Tensor, src: Tensor, broadcast: bool) -> Tensor:
     L.check(L.lib().gmp_row_fill(_ptr(dst), _ptr(idx), _ptr(src), idx.numel(), dst.size(0), F, int(broadcast), _stream(dst)),
             "gmp_row_fill")
     return dst
+
+
+# ---- device-side augmentation and masking (csrc/augment.hip) ---------------------------------------------
+def view_sizes(ptr_host) -> Tuple[list, list]:
+    """Per-graph kept-node counts of an augmented view and masked-node counts of node-feature masking: functions of the graph
+    sizes alone (augmentations.py:49-50, pretrain_model.py:75-76), so the host lays out offsets without asking the device."""
+    n = [int(b - a) for a, b in zip(ptr_host[:-1], ptr_host[1:])]
+    kept = [v - max(1, int(v * 0.2)) if v >= 3 else v for v in n]
+    masked = [max(1, int(v * 0.15)) if v >= 3 else 0 for v in n]
+    return kept, masked
+
+
+class DeviceViews(NamedTuple):
+    """gmp_aug_two_views outputs of one domain batch (all on the device): per view rows / rowmask / edges [2, ecap] / common, plus
+    counts [3G] (edges view 1, edges view 2, common, per graph) and totals [5] (E1, E2, common, mask flag 1, mask flag 2)."""
+    rows: Tuple[Tensor, Tensor]
+    rowmask: Tuple[Tensor, Tensor]
+    edges: Tuple[Tensor, Tensor]
+    common: Tuple[Tensor, Tensor]
+    counts: Tensor
+    totals: Tensor
+    view_ptr: list
+
+
+def aug_node_masks(ptr: Tensor, ptr_host, seed: int, stream_id: int) -> Tensor:
+    """Node-feature-masking indices of a domain batch, drawn on the device (pretrain_model.py:71-80's per-graph loop)."""
+    _need(ptr, torch.int64, "ptr", 1)
+    _, masked = view_sizes(ptr_host)
+    off = [0]
+    for m in masked:
+        off.append(off[-1] + m)
+    out = torch.empty(off[-1], dtype=torch.int64, device=ptr.device)
+    if off[-1] == 0:
+        return out
+    out_ptr = torch.tensor(off, dtype=torch.int64).to(ptr.device)
+    G = len(ptr_host) - 1
+    L.check(L.lib().gmp_aug_node_masks(_ptr(ptr), _ptr(out_ptr), G, max(int(b - a) for a, b in zip(ptr_host[:-1], ptr_host[1:])),
+                                       seed & (2 ** 64 - 1), stream_id & 0xffffffff, _ptr(out), _stream(ptr)), "gmp_aug_node_masks")
+    return out
+
+
+def aug_two_views(ptr: Tensor, eptr: Tensor, edge_index: Tensor, ptr_host, eptr_host, num_features: int, seed: int,
+                  stream_id: int) -> DeviceViews:
+    """GraphAugmentor.create_two_views (augmentations.py:88-111) of a domain batch on the device."""
+    _need(ptr, torch.int64, "ptr", 1); _need(eptr, torch.int64, "eptr", 1); _need(edge_index, torch.int64, "edge_index", 2)
+    dev, G = ptr.device, len(ptr_host) - 1
+    N, E = int(ptr_host[-1]), int(edge_index.size(1))
+    kept, _ = view_sizes(ptr_host)
+    vp = [0]
+    for k in kept:
+        vp.append(vp[-1] + k)
+    vptr = torch.tensor(vp, dtype=torch.int64).to(dev)
+    mk = lambda n, dt=torch.int64: torch.empty(n, dtype=dt, device=dev)
+    rows, masks = (mk(vp[-1]), mk(vp[-1])), (mk(vp[-1]), mk(vp[-1]))
+    edges, common = (mk(2 * max(E, 1)).view(2, -1), mk(2 * max(E, 1)).view(2, -1)), (mk(vp[-1]), mk(vp[-1]))
+    counts, totals = mk(3 * max(G, 1), torch.int32), mk(5, torch.int32)
+    l = L.lib()
+    ws = _ws(l.gmp_aug_workspace_bytes(N, E, G), dev)
+    L.check(l.gmp_aug_two_views(_ptr(ptr), _ptr(eptr), _ptr(edge_index.contiguous()), N, E, _ptr(vptr), G,
+                                max([int(b - a) for a, b in zip(ptr_host[:-1], ptr_host[1:])] + [0]),
+                                max([int(b - a) for a, b in zip(eptr_host[:-1], eptr_host[1:])] + [0]), num_features,
+                                seed & (2 ** 64 - 1), stream_id & 0xffffffff, _ptr(rows[0]), _ptr(rows[1]), _ptr(masks[0]), _ptr(masks[1]),
+                                _ptr(edges[0]), _ptr(edges[1]), max(E, 1), _ptr(common[0]), _ptr(common[1]), _ptr(counts), _ptr(totals),
+                                _ptr(ws), ws.numel(), _stream(ptr)), "gmp_aug_two_views")
+    return DeviceViews(rows, masks, edges, common, counts, totals, vp)

@@ -432,6 +432,30 @@ int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, in
  * computed from incomplete gradients; the host sees the flag at its next check_gates(). */
 
 
+/* ---- device-side augmentation and masking ------------------------------------------------------------
+ * The per-graph loops of src/pretrain/augmentations.py:17-111 (GraphAugmentor.create_two_views: node drop, subgraph relabel,
+ * edge drop, attribute mask, common-node masks) and of src/models/pretrain_model.py:71-80 (mask indices) over a whole domain batch.
+ * Random subsets are "the k smallest Philox keys of the graph" (seed, stream_id, element id): the reference's distributions, not its
+ * mt19937 stream -- the bit-exact replay of that stream stays on the host (csrc_host/hostdraw.cpp).  All index arrays are int64
+ * like the reference's; graphs are given as offset arrays (ptr / eptr: [G + 1]) over a batch in batch-local numbering.
+ *
+ * gmp_aug_node_masks: out_idx[out_ptr[g] ...] = the max(1, int(.15 n_g)) masked nodes of graph g (n_g >= 3), ascending; out_ptr is the
+ *   caller's exclusive scan of those counts (they depend on the graph sizes only).
+ * gmp_aug_two_views: both views of every graph.  view_ptr = exclusive scan of the kept-node counts n_g - max(1, int(.2 n_g)) (n_g >= 3,
+ *   else n_g), the same for both views.  Outputs per view: rows [view_ptr[G]] (kept nodes, batch numbering, ascending), rowmask
+ *   (bit c = column c zeroed, per row), edges [2, edge_capacity] (view numbering; PyG subgraph(relabel_nodes=True) order, minus the
+ *   dropped ones), common (view-local ids of nodes kept in BOTH views); counts [3 G] = edges of view 1 / view 2 / common nodes per
+ *   graph; totals_and_flags [5] = total edges of view 1, of view 2, total common nodes, "some graph of view 1 / 2 drew an attribute
+ *   mask".  Limits: 4,096 nodes and 8,192 edges per graph, 64 feature columns. */
+size_t gmp_aug_workspace_bytes(int64_t num_nodes, int64_t num_edges, int num_graphs);
+int gmp_aug_node_masks(const int64_t* ptr, const int64_t* out_ptr, int num_graphs, int64_t max_graph_nodes, uint64_t seed,
+                       uint32_t stream_id, int64_t* out_idx, gmp_stream_t stream);
+int gmp_aug_two_views(const int64_t* ptr, const int64_t* eptr, const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
+                      const int64_t* view_ptr, int num_graphs, int64_t max_graph_nodes, int64_t max_graph_edges, int num_features,
+                      uint64_t seed, uint32_t stream_id, int64_t* rows1, int64_t* rows2, uint64_t* rowmask1, uint64_t* rowmask2,
+                      int64_t* edges1, int64_t* edges2, int64_t edge_capacity, int64_t* common1, int64_t* common2, int32_t* counts,
+                      int32_t* totals_and_flags, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
