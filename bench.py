@@ -39,11 +39,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
-    ap.add_argument("--rng", choices=["reference", "vectorized"], default=None,
+    ap.add_argument("--rng", choices=["reference", "vectorized", "device"], default=None,
                     help="how the step's augmentation/mask/negative indices are drawn: 'reference' = the exact "
                          "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
-                         "distributions, all graphs of a domain at once (numpy).  Default: reference when the native host module "
-                         "is built, else vectorized")
+                         "distributions, all graphs of a domain at once (numpy); 'device' = masks and views built on the GPU "
+                         "(csrc/augment.hip, Philox).  Default: reference when the native host module is built, else vectorized")
     return ap.parse_args(argv)
 
 
@@ -376,7 +376,8 @@ def main() -> None:
             "config": {"workload": "s4 (NFM+LP+NC+GC+GP) pre-training step, 4 domains x 8 synthetic ENZYMES-shaped graphs "
                                    "per rank (input dims 7/4/37/21, hidden 256, 5 GIN layers), PCGrad + clip + AdamW",
                        "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "setup_steps": PRIME_STEPS, "index_rng": a.rng,
-                       "index_draws": "native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else "python/numpy",
+                       "index_draws": ("native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else
+                                       "device (csrc/augment.hip; negatives on the host)" if a.rng == "device" else "python/numpy"),
                        "cross_stream_sync": "gates" if engine.use_gates else "events", "gates_verified_under_communicator": gates_checked,
                        "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                        "devices_visible": torch.cuda.device_count(),

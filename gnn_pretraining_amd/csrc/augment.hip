@@ -21,6 +21,7 @@ namespace {
 
 constexpr int AB = 256;                 // threads per graph
 constexpr int MAX_NODES = 4096;         // per graph: keep flags / new ids / keys of both views live in LDS
+constexpr int EDGES_LDS = 4096;
 constexpr uint32_t S_NODE = 0x6e6f6465u, S_EDGE = 0x65646765u, S_ECOIN = 0x65636f69u, S_ACOIN = 0x61636f69u, S_ATTR = 0x61747472u,
                    S_NFM = 0x6e666d6bu;
 
@@ -78,16 +79,25 @@ struct ViewArgs {
     int64_t* slot_common[2];     // [N] common nodes of graph g compacted at ptr[g], graph-local new ids of that view
     int32_t* edge_count[2];      // [G]
     int32_t* common_count;       // [G] (the same for both views)
-    int32_t* any_mask;           // [2] set when any graph of the view drew an attribute mask
+    int32_t* mask_flag[2];       // [G] this graph drew an attribute mask in view v
     uint32_t* ekey;              // [E] scratch: key of a surviving edge (a graph's block only touches its own range)
     uint8_t* eflag;              // [E] scratch: survives node drop / survives edge drop
 };
 
-__global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a) {
-    __shared__ uint32_t keys[MAX_NODES];
-    __shared__ uint16_t newid[2][MAX_NODES];        // 0xffff = dropped
-    __shared__ int s_cnt[4];
-    __shared__ unsigned long long s_bits;
+// LDS is sized per launch from the batch's largest graph (ncap nodes, ecap edges; a few KB for TUDataset graphs): these blocks run
+// beside the step's GEMMs, whose 64 KB blocks leave little LDS free on a CU -- a 56 KB static footprint waited for a GEMM block to
+// retire before it could start (58 us per launch in the step against ~10 alone)
+__global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a, int ncap, int ecap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    unsigned long long* const s_bits_p = reinterpret_cast<unsigned long long*>(dyn);
+    int* const s_cnt = reinterpret_cast<int*>(dyn + 8);
+    uint32_t* const keys = reinterpret_cast<uint32_t*>(dyn + 32);
+    uint32_t* const s_ekey = keys + ncap;           // edge keys / flags of the graph: in LDS when they fit (every TUDataset graph does),
+    uint16_t* const newid0 = reinterpret_cast<uint16_t*>(s_ekey + ecap);      // in the workspace otherwise: the rank loops are latency-bound
+    uint16_t* const newid1 = newid0 + ncap;                                   // new ids per view; 0xffff = dropped
+    uint8_t* const s_eflag = reinterpret_cast<uint8_t*>(newid1 + ncap);
+    uint16_t* const newid[2] = {newid0, newid1};
+#define s_bits (*s_bits_p)
     const int g = blockIdx.x, t = threadIdx.x;
     const int64_t s = a.ptr[g], es = a.eptr[g];
     const int n = (int)(a.ptr[g + 1] - s), ne = (int)(a.eptr[g + 1] - es);
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a) {
         }
         __syncthreads();
         const uint64_t bits = s_bits;
-        if (t == 0 && bits) atomicOr(a.any_mask + v, 1);
+        if (t == 0) a.mask_flag[v][g] = bits != 0ull;
         for (int i = t; i < n; i += AB) {
             if (newid[v][i] == 0xffff) continue;
             const int id = (int)keys[i];
@@ -151,6 +161,8 @@ __global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a) {
     }
     // ---- edges: subgraph() keeps an edge when both endpoints stay (order preserved); then, if the coin falls and at least 3 are
     // left, the E' - max(1, int(.2 E')) smallest edge keys stay (kept in their original order)
+    uint32_t* const ekey = ne <= ecap ? s_ekey : a.ekey + es;          // (generic pointers: LDS or global)
+    uint8_t* const eflag = ne <= ecap ? s_eflag : a.eflag + es;
     for (int v = 0; v < 2; ++v) {
         __syncthreads();
         if (t == 0) s_cnt[0] = 0;
@@ -159,8 +171,8 @@ __global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a) {
         for (int e = t; e < ne; e += AB) {
             const int i = (int)(a.src[es + e] - s), j = (int)(a.dst[es + e] - s);
             const bool al = newid[v][i] != 0xffff && newid[v][j] != 0xffff;
-            a.eflag[es + e] = al;
-            a.ekey[es + e] = al ? key32(a.seed, a.stream + v, S_EDGE, (uint64_t)(es + e)) : 0u;
+            eflag[e] = al;
+            ekey[e] = al ? key32(a.seed, a.stream + v, S_EDGE, (uint64_t)(es + e)) : 0u;
             alive_mine += al;
         }
         atomicAdd(&s_cnt[0], alive_mine);
@@ -173,30 +185,31 @@ __global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a) {
             uint8_t mine[(8192 + AB - 1) / AB];      // this thread's verdicts (ne <= 8192 is checked by the host wrapper)
             int m = 0;
             for (int e = t; e < ne; e += AB, ++m) {
-                bool kept = a.eflag[es + e];
+                bool kept = eflag[e];
                 if (kept) {
-                    const uint32_t ke = a.ekey[es + e];
+                    const uint32_t ke = ekey[e];
                     int rank = 0;
-                    for (int q = 0; q < ne; ++q) rank += a.eflag[es + q] && ((a.ekey[es + q] < ke) || (a.ekey[es + q] == ke && q < e));
+                    for (int q = 0; q < ne; ++q) rank += eflag[q] && ((ekey[q] < ke) || (ekey[q] == ke && q < e));
                     kept = rank < keep_e;
                 }
                 mine[m] = kept;
             }
             __syncthreads();                          // every rank is taken before any flag changes
             m = 0;
-            for (int e = t; e < ne; e += AB, ++m) a.eflag[es + e] = mine[m];
+            for (int e = t; e < ne; e += AB, ++m) eflag[e] = mine[m];
             __threadfence_block();
             __syncthreads();
         }
         for (int e = t; e < ne; e += AB) {           // position among the kept edges = kept edges in front (original order preserved)
-            if (!a.eflag[es + e]) continue;
+            if (!eflag[e]) continue;
             int pos = 0;
-            for (int q = 0; q < e; ++q) pos += a.eflag[es + q];
+            for (int q = 0; q < e; ++q) pos += eflag[q];
             a.slot_src[v][es + pos] = newid[v][(int)(a.src[es + e] - s)];
             a.slot_dst[v][es + pos] = newid[v][(int)(a.dst[es + e] - s)];
         }
         if (t == 0) a.edge_count[v][g] = keep_e;
     }
+#undef s_bits
 }
 
 struct EmitArgs {
@@ -207,10 +220,11 @@ struct EmitArgs {
     const int64_t* slot_common[2];
     const int32_t* edge_count[2];
     const int32_t* common_count;
+    const int32_t* mask_flag[2];
     int64_t* edges[2];          // [2, ecap]: row 0 at edges[v], row 1 at edges[v] + ecap
     int64_t ecap;
     int64_t* common[2];
-    int32_t* totals;            // [3]: edges of view 0, edges of view 1, common nodes
+    int32_t* totals;            // [5]: edges of view 0, edges of view 1, common nodes, any attribute mask in view 0 / view 1
 };
 
 // slots -> final offsets (exclusive scan of the per-graph counts), graph-local new ids -> view numbering (+ vptr[g])
@@ -233,7 +247,14 @@ __global__ __launch_bounds__(AB) void emit_views_kernel(const EmitArgs a) {
         a.common[0][coff + c] = a.slot_common[0][a.ptr[g] + c] + a.vptr[g];
         a.common[1][coff + c] = a.slot_common[1][a.ptr[g] + c] + a.vptr[g];
     }
-    if (g == a.G - 1 && t == 0) a.totals[2] = (int32_t)(coff + cc);
+    if (g == a.G - 1 && t == 0) {
+        a.totals[2] = (int32_t)(coff + cc);
+        for (int v = 0; v < 2; ++v) {           // (written by every launch: no memset in front of the kernels)
+            int any = 0;
+            for (int q = 0; q < a.G; ++q) any |= a.mask_flag[v][q];
+            a.totals[3 + v] = any;
+        }
+    }
 }
 
 }  // namespace
@@ -279,13 +300,16 @@ extern "C" int gmp_aug_two_views(const int64_t* ptr, const int64_t* eptr, const 
     a.ekey = (uint32_t*)(a.slot_common[1] + num_nodes);
     a.eflag = (uint8_t*)(a.ekey + num_edges);
     a.edge_count[0] = counts; a.edge_count[1] = counts + num_graphs; a.common_count = counts + 2 * num_graphs;
-    a.any_mask = totals_and_flags + 3;
-    if (hipMemsetAsync(totals_and_flags, 0, 5 * sizeof(int32_t), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "aug_two_views: memset");
-    hipLaunchKernelGGL(two_views_kernel, dim3(num_graphs), dim3(AB), 0, st, a);
+    a.mask_flag[0] = counts + 3 * num_graphs; a.mask_flag[1] = counts + 4 * num_graphs;
+    const int ncap = (int)((max_graph_nodes + 63) / 64 * 64);
+    const int ecap = max_graph_edges <= EDGES_LDS ? (int)((max_graph_edges + 63) / 64 * 64) : 0;
+    const size_t lds = 32 + (size_t)ncap * 4 + (size_t)ecap * 4 + (size_t)ncap * 4 + (size_t)ecap + 64;
+    hipLaunchKernelGGL(two_views_kernel, dim3(num_graphs), dim3(AB), lds, st, a, ncap, ecap);
     EmitArgs e{};
     e.ptr = ptr; e.eptr = eptr; e.vptr = view_ptr; e.G = num_graphs;
     for (int v = 0; v < 2; ++v) { e.slot_src[v] = a.slot_src[v]; e.slot_dst[v] = a.slot_dst[v]; e.slot_common[v] = a.slot_common[v]; e.edge_count[v] = a.edge_count[v]; }
     e.common_count = a.common_count;
+    e.mask_flag[0] = a.mask_flag[0]; e.mask_flag[1] = a.mask_flag[1];
     e.edges[0] = edges1; e.edges[1] = edges2; e.ecap = edge_capacity; e.common[0] = common1; e.common[1] = common2; e.totals = totals_and_flags;
     hipLaunchKernelGGL(emit_views_kernel, dim3(num_graphs), dim3(AB), 0, st, e);
     return gmp::check_launch("aug_two_views kernels");

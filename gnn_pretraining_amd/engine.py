@@ -95,6 +95,24 @@ class StepInputs:
         self.x_all = x.to(device, non_blocking=pin)
         g = torch.cat(gp)
         self.graph_props = (g.pin_memory() if pin else g).to(device, non_blocking=pin)           # [sum B, 12] in domain order
+        self.device = torch.device(device)
+        self._dev_graph: Dict[str, tuple] = {}
+
+    def dev_graph(self, d: str):
+        """(ptr, eptr, edge_index, view_ptr, mask_ptr) of domain d's batch as int64 device tensors (batch-local numbering; view_ptr /
+        mask_ptr = exclusive scans of the per-graph kept-node / masked-node counts, functions of the graph sizes alone) + the two scans
+        as numpy arrays -- what the device-side augmentation kernels read; uploaded once per input, on first use (a pageable-memory
+        upload synchronises with the stream it is made on: never do it per step)."""
+        t = self._dev_graph.get(d)
+        if t is None:
+            hb = self.host[d]
+            dev = self.device
+            kept, masked = L_view_sizes(hb.ptr_host)
+            vptr = np.concatenate([[0], np.cumsum(kept)]).astype(np.int64)
+            moff = np.concatenate([[0], np.cumsum(masked)]).astype(np.int64)
+            t = self._dev_graph[d] = (torch.tensor(hb.ptr_host, dtype=torch.long).to(dev), torch.tensor(hb.edge_ptr_host, dtype=torch.long).to(dev),
+                                      hb.edge_index.contiguous().to(dev), torch.from_numpy(vptr).to(dev), torch.from_numpy(moff).to(dev), vptr, moff)
+        return t
 
 
 class StepPlan:
@@ -123,6 +141,20 @@ def device_views_to_host(dv) -> Tuple["ViewArrays", "ViewArrays"]:
         out.append(ViewArrays(dv.rows[v].cpu().numpy(), dv.edges[v][:, :tot[v]].cpu().numpy(), np.asarray(dv.view_ptr, dtype=np.int64),
                               rm, dv.common[v][:tot[2]].cpu().numpy()))
     return out[0], out[1]
+
+
+class DrawTicket:
+    """One step's device-side draws in flight: the pinned slot they land in, where each (task, domain) piece sits, the flag value
+    that says they have landed (StepEngine.enqueue_draws / collect_draws)."""
+    __slots__ = ("slot", "layout", "epoch")
+
+    def __init__(self, slot, layout, epoch) -> None:
+        self.slot, self.layout, self.epoch = slot, layout, epoch
+
+
+def L_view_sizes(ptr_host):
+    from .ops import view_sizes
+    return view_sizes(ptr_host)
 
 
 _HOSTDRAW, _HOSTDRAW_TRIED = None, False
@@ -168,8 +200,8 @@ class StepEngine:
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
                  grad_sync=None, rng_mode: str = "reference", native: bool = True, neg_rng: Optional[random.Random] = None) -> None:
         self.native = native       # True: csrc/step.hip enqueues the step; False: the same launches one by one from Python
-        if rng_mode not in ("reference", "vectorized"):
-            raise ValueError("rng_mode must be 'reference' or 'vectorized'")
+        if rng_mode not in ("reference", "vectorized", "device"):
+            raise ValueError("rng_mode must be 'reference', 'vectorized' or 'device'")
         self.rng_mode, self._nprng = rng_mode, None
         # Link-prediction negatives: PyG's sampler draws from Python's `random` (the global, unseeded module in the reference), never
         # from the shared torch generator (pretrain/tasks.py sample_negative_edges).  The engine keeps a stream of its own.
@@ -397,6 +429,8 @@ class StepEngine:
         drawn for all graphs of a domain at once with numpy (different stream, ~10x less host time)."""
         if self.rng_mode == "vectorized":
             return self._draw_vectorized(inp, gen)
+        if self.rng_mode == "device":
+            return self.collect_draws(inp, self.enqueue_draws(inp))
         art: Dict[str, object] = {}
         host = {d: inp.host[d] for d in self.domains}
         H = hostdraw()
@@ -499,6 +533,119 @@ class StepEngine:
             out.append(ViewArrays(np.concatenate(a["rows"]), np.concatenate(a["edges"], axis=1), np.asarray(a["ptr"], dtype=np.int64),
                                   rm if rm.any() else None, np.concatenate(a["common"])))
         return out[0], out[1]
+
+    # ---- device draws (csrc/augment.hip): masks and views built on the GPU, one ticket per step ----------------------------
+    DRAW_SLOTS = 8
+
+    def enqueue_draws(self, inp: StepInputs) -> "DrawTicket":
+        """Enqueue the device-side draws of ONE step (rng_mode 'device'): node-feature-masking indices and the two augmented views
+        of every contrastive (task, domain) pair, by gmp_aug_node_masks / gmp_aug_two_views on the aux stream, followed by one copy
+        kernel that writes the results into a pinned host slot and a one-thread kernel that raises the slot's flag.  Safe to call
+        from the prefetch thread while the launcher thread enqueues steps: the kernels depend on nothing a step computes, and
+        wherever they land between the aux stream's packets they run at most one step later.  Returns the ticket
+        collect_draws() waits on."""
+        if not hasattr(self, "_draw_slots"):
+            self._draw_slots, self._draw_count, self._draw_ws, self._draw_graveyard = [], 0, None, []
+        k = self._draw_count
+        self._draw_count += 1
+        lay, off = [], 0
+
+        def take(nbytes: int) -> int:
+            nonlocal off
+            o = off
+            off += (nbytes + 15) // 16 * 16
+            return o
+
+        for t in self.tasks:
+            if t not in ("node_feat_mask", "node_contrast", "graph_contrast"):
+                continue
+            for d in self.domains:
+                hb = inp.host[d]
+                G, N, E = hb.num_graphs, hb.num_nodes, hb.num_edges
+                if G == 0 or (t == "graph_contrast" and G < 2):
+                    continue
+                _, _, _, _, _, vptr_h, moff_h = inp.dev_graph(d)
+                if t == "node_feat_mask":
+                    lay.append((t, d, {"idx": take(8 * int(moff_h[-1])), "m": int(moff_h[-1])}))
+                else:
+                    V = int(vptr_h[-1])
+                    lay.append((t, d, {"rows": (take(8 * V), take(8 * V)), "mask": (take(8 * V), take(8 * V)),
+                                       "edges": (take(16 * max(E, 1)), take(16 * max(E, 1))), "common": (take(8 * V), take(8 * V)),
+                                       "counts": take(20 * G), "totals": take(32), "V": V, "E": E, "vptr": vptr_h}))
+        total = max(off, 16)
+        slot_id = k % self.DRAW_SLOTS
+        while len(self._draw_slots) <= slot_id:
+            self._draw_slots.append(None)
+        slot = self._draw_slots[slot_id]
+        if slot is None or slot["dev"].numel() < total:
+            cap = max(total * 2, 1 << 20)
+            self._draw_graveyard.append(slot)
+            slot = self._draw_slots[slot_id] = {"dev": torch.empty(cap, dtype=torch.uint8, device=self.device),
+                                                "pin": torch.empty(cap, dtype=torch.uint8).pin_memory(),
+                                                "flag": torch.zeros(4, dtype=torch.int32).pin_memory()}
+        lib, aux = self.lib, self.aux_stream.cuda_stream
+        base = slot["dev"].data_ptr()
+        seed = (self.seed * 1000003 + 0x5bd1e995 * (k + 1)) & (2 ** 64 - 1)
+        if True:
+            for (t, d, o) in lay:
+                ptr, eptr, ei, vptr, optr, _, _ = inp.dev_graph(d)
+                hb = inp.host[d]
+                sid = 16 * self.tasks.index(t) + 2 * self.domains.index(d) * len(self.tasks) * 16
+                nmax = max(int(b - a) for a, b in zip(hb.ptr_host[:-1], hb.ptr_host[1:]))
+                if t == "node_feat_mask":
+                    if o["m"]:
+                        self._chk(lib.gmp_aug_node_masks(ptr.data_ptr(), optr.data_ptr(), hb.num_graphs, nmax, seed, sid, base + o["idx"], aux), "aug_node_masks")
+                else:
+                    need = lib.gmp_aug_workspace_bytes(hb.num_nodes, o["E"], hb.num_graphs)
+                    if self._draw_ws is None or self._draw_ws.numel() < need:
+                        # (kernels of earlier tickets may still be using the old one on the aux stream: keep it alive)
+                        self._draw_graveyard.append(self._draw_ws)
+                        self._draw_ws = torch.empty(max(2 * need, lib.gmp_aug_workspace_bytes(self.max_rows, self.max_edges, 1024)),
+                                                    dtype=torch.uint8, device=self.device)
+                    emax = max([int(b - a) for a, b in zip(hb.edge_ptr_host[:-1], hb.edge_ptr_host[1:])] + [0])
+                    self._chk(lib.gmp_aug_two_views(ptr.data_ptr(), eptr.data_ptr(), ei.data_ptr(), hb.num_nodes, o["E"], vptr.data_ptr(), hb.num_graphs,
+                                                    nmax, emax, int(hb.x.size(1)), seed, sid, base + o["rows"][0], base + o["rows"][1],
+                                                    base + o["mask"][0], base + o["mask"][1], base + o["edges"][0], base + o["edges"][1], max(o["E"], 1),
+                                                    base + o["common"][0], base + o["common"][1], base + o["counts"], base + o["totals"],
+                                                    self._draw_ws.data_ptr(), self._draw_ws.numel(), aux), "aug_two_views")
+            src = (C.c_void_p * 1)(base)
+            dst = (C.c_void_p * 1)(slot["pin"].data_ptr())
+            self._chk(lib.gmp_upload(1, src, dst, (C.c_int64 * 1)((total + 15) // 16 * 16), aux), "draw results -> pinned host")
+            self._chk(lib.gmp_gate_open(slot["flag"].data_ptr(), k + 1, aux), "draw flag")
+        return DrawTicket(slot, lay, k + 1)
+
+    def collect_draws(self, inp: StepInputs, ticket: "DrawTicket") -> Dict[str, object]:
+        """Wait for a ticket's flag (a word in pinned host memory the GPU sets behind its copy: no HIP call, no stream sync) and wrap
+        the slot's arrays as the step's artefacts.  Link-prediction negatives stay on the host (mostly "every non-edge", no draw)."""
+        import time as _t
+        flag = ticket.slot["flag"].numpy()
+        t_end = _t.time() + 120.0
+        while int(flag[0]) < ticket.epoch:
+            if _t.time() > t_end:
+                raise L.GnnmpError("engine: device draws did not arrive within two minutes")
+            _t.sleep(2e-5)
+        buf = ticket.slot["pin"].numpy()
+        art: Dict[str, object] = {}
+        for t in self.tasks:
+            if t == "link_pred":
+                art[t] = {d: (_EMPTY_ART[t]() if not inp.host[d].num_graphs else self._negatives(inp.host[d])) for d in self.domains}
+            elif t in ("node_feat_mask", "node_contrast", "graph_contrast"):
+                art[t] = {d: _EMPTY_ART[t]() for d in self.domains}        # domains without a drawn piece (no graphs / too few)
+        for (t, d, o) in ticket.layout:
+            if t == "node_feat_mask":
+                art[t][d] = buf[o["idx"]:o["idx"] + 8 * o["m"]].view(np.int64).copy()
+            else:
+                tot = buf[o["totals"]:o["totals"] + 20].view(np.int32)
+                views = []
+                for v in range(2):
+                    V, e = o["V"], int(tot[v])
+                    rows = buf[o["rows"][v]:o["rows"][v] + 8 * V].view(np.int64).copy()
+                    ed = buf[o["edges"][v]:o["edges"][v] + 16 * max(o["E"], 1)].view(np.int64).reshape(2, -1)[:, :e].copy()
+                    rm = buf[o["mask"][v]:o["mask"][v] + 8 * V].view(np.uint64).copy() if tot[3 + v] else None
+                    cm = buf[o["common"][v]:o["common"][v] + 8 * int(tot[2])].view(np.int64).copy()
+                    views.append(ViewArrays(rows, ed, o["vptr"], rm, cm))
+                art[t][d] = (views[0], views[1])
+        return art
 
     # ---- vectorized draws (same distributions, numpy stream) --------------------------------------------
     def _np_rng(self, gen: torch.Generator) -> np.random.Generator:
@@ -778,9 +925,10 @@ class StepEngine:
         return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site)
 
     # ------------------------------------------------------------------ one step
-    def prepare(self, inp: StepInputs, gen: torch.Generator):
-        """Host half of a step (all RNG draws + the segment layout); may run on another thread ahead of time."""
-        art = self.draw(inp, gen)
+    def prepare(self, inp: StepInputs, gen: torch.Generator, ticket: Optional[DrawTicket] = None):
+        """Host half of a step (all RNG draws + the segment layout); may run on another thread ahead of time.  `ticket`: the
+        device-side draws of this input, enqueued earlier (rng_mode 'device'; StepPrefetcher keeps a few inputs' tickets in flight)."""
+        art = self.collect_draws(inp, ticket) if ticket is not None else self.draw(inp, gen)
         return art, self.plan(inp, art)
 
     def step(self, inp: StepInputs, gen: torch.Generator, art: Optional[Dict[str, object]] = None,
@@ -789,6 +937,16 @@ class StepEngine:
         self.loss_sums / self.plan_sizes until someone asks (losses())."""
         import time as _t
         self._use_stream()
+        if self.rng_mode == "device" or os.environ.get("GMP_FORCE_LEAD"):
+            # Device draws ride the aux stream, i.e. they run behind whatever the launcher has already enqueued there: the launcher
+            # therefore keeps at most two steps in front of the GPU (enough to keep it fed: enqueueing a step takes half a step), so a
+            # ticket is served within two steps and the prefetcher's three tickets in flight cover it
+            lead = getattr(self, "_lead", None)
+            if lead is None:
+                lead = self._lead = {}
+            ev = lead.pop(self.step_count - int(os.environ.get("GMP_DEVICE_LEAD", "2")), None)
+            if ev is not None:
+                ev.synchronize()
         t0 = _t.perf_counter()
         if prepared is not None:
             art, p = prepared
@@ -811,6 +969,10 @@ class StepEngine:
         h = self.host_ms
         h["draw"] += (t1 - t0) * 1e3; h["plan"] += (t2 - t1) * 1e3; h["upload"] += (t3 - t2) * 1e3; h["launch"] += (t4 - t3) * 1e3
         h["steps"] += 1
+        if self.rng_mode == "device" or os.environ.get("GMP_FORCE_LEAD"):
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(self.device))
+            self._lead[self.step_count] = e
         self.step_count += 1
         self.last_plan, self.last_inputs = p, inp
         if self.model.training:                      # BatchNorm call counters (one per forward() the reference would have made)
@@ -1619,6 +1781,29 @@ class StepPrefetcher:
         def work() -> None:
             import time as _t
             try:
+                if engine.rng_mode == "device":
+                    # the draws of the next LOOK inputs are in flight on the GPU while this thread plans the current one: a ticket
+                    # enqueued on the aux stream runs within one step, and this thread is `depth` steps ahead of the launcher
+                    from collections import deque
+                    LOOK, ahead, it = 3, deque(), iter(inputs)
+                    done = False
+                    while True:
+                        while not done and len(ahead) < LOOK:
+                            try:
+                                nxt = next(it)
+                            except StopIteration:
+                                done = True
+                                break
+                            ahead.append((nxt, engine.enqueue_draws(nxt)))
+                        if not ahead:
+                            break
+                        inp, ticket = ahead.popleft()
+                        t0 = _t.perf_counter()
+                        item = (inp, engine.prepare(inp, gen, ticket))
+                        self.busy_s += _t.perf_counter() - t0
+                        self.q.put(item)
+                    self.q.put(None)
+                    return
                 for inp in inputs:
                     t0 = _t.perf_counter()
                     item = (inp, engine.prepare(inp, gen))

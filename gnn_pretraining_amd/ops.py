@@ -504,7 +504,7 @@ def aug_two_views(ptr: Tensor, eptr: Tensor, edge_index: Tensor, ptr_host, eptr_
     mk = lambda n, dt=torch.int64: torch.empty(n, dtype=dt, device=dev)
     rows, masks = (mk(vp[-1]), mk(vp[-1])), (mk(vp[-1]), mk(vp[-1]))
     edges, common = (mk(2 * max(E, 1)).view(2, -1), mk(2 * max(E, 1)).view(2, -1)), (mk(vp[-1]), mk(vp[-1]))
-    counts, totals = mk(3 * max(G, 1), torch.int32), mk(5, torch.int32)
+    counts, totals = mk(5 * max(G, 1), torch.int32), mk(5, torch.int32)
     l = L.lib()
     ws = _ws(l.gmp_aug_workspace_bytes(N, E, G), dev)
     L.check(l.gmp_aug_two_views(_ptr(ptr), _ptr(eptr), _ptr(edge_index.contiguous()), N, E, _ptr(vptr), G,

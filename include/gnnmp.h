@@ -444,8 +444,8 @@ int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, in
  * gmp_aug_two_views: both views of every graph.  view_ptr = exclusive scan of the kept-node counts n_g - max(1, int(.2 n_g)) (n_g >= 3,
  *   else n_g), the same for both views.  Outputs per view: rows [view_ptr[G]] (kept nodes, batch numbering, ascending), rowmask
  *   (bit c = column c zeroed, per row), edges [2, edge_capacity] (view numbering; PyG subgraph(relabel_nodes=True) order, minus the
- *   dropped ones), common (view-local ids of nodes kept in BOTH views); counts [3 G] = edges of view 1 / view 2 / common nodes per
- *   graph; totals_and_flags [5] = total edges of view 1, of view 2, total common nodes, "some graph of view 1 / 2 drew an attribute
+ *   dropped ones), common (view-local ids of nodes kept in BOTH views); counts [5 G] = edges of view 1 / view 2 / common nodes /
+ *   "drew an attribute mask" in view 1 / view 2, per graph; totals_and_flags [5] = total edges of view 1, of view 2, total common nodes, "some graph of view 1 / 2 drew an attribute
  *   mask".  Limits: 4,096 nodes and 8,192 edges per graph, 64 feature columns. */
 size_t gmp_aug_workspace_bytes(int64_t num_nodes, int64_t num_edges, int num_graphs);
 int gmp_aug_node_masks(const int64_t* ptr, const int64_t* out_ptr, int num_graphs, int64_t max_graph_nodes, uint64_t seed,

@@ -492,3 +492,43 @@ def test_a_raised_gate_error_flag_blocks_the_update():
     eng.step(inp, gen, order=list(tasks))
     torch.cuda.synchronize()
     assert not torch.equal(eng.flat, p0)
+
+
+def test_device_rng_mode_draws_valid_artefacts_and_trains():
+    """rng_mode 'device' (SURVEY.md section 8 f1): masks and augmented views are built on the GPU (csrc/augment.hip), shipped to the
+    planner through pinned memory; the artefacts obey the reference's structural rules, the step they feed matches the oracle run
+    on the same artefacts, and the prefetcher keeps several inputs' draws in flight."""
+    from gnn_pretraining_amd.engine import StepPrefetcher
+    om, hm, eng, host, inp, gen, tasks, domains = build("s4", 191, rng_mode="device")
+    art = eng.draw(inp, gen)
+    for d, b in host.items():
+        n = np.diff(np.asarray(b.ptr_host))
+        idx = art["node_feat_mask"][d]
+        assert len(np.unique(idx)) == len(idx) == int(np.where(n >= 3, np.maximum(1, (n * .15).astype(int)), 0).sum())
+        for t in ("node_contrast", "graph_contrast"):
+            v1, v2 = art[t][d]
+            for v in (v1, v2):
+                assert np.array_equal(np.diff(v.ptr), np.where(n >= 3, n - np.maximum(1, (n * .2).astype(int)), n))
+                assert (np.diff(v.rows) > 0).all() and v.edges.max(initial=-1) < v.ptr[-1]
+            assert np.array_equal(v1.rows[v1.common], np.intersect1d(v1.rows, v2.rows))
+        # the node- and graph-level contrastive tasks draw their own views (tasks.py:150,233)
+        assert not np.array_equal(art["node_contrast"][d][0].rows, art["graph_contrast"][d][0].rows)
+    eng.temperature = 0.37
+    eng.step(inp, gen, art=art, order=list(tasks), apply_update=False)
+    got = eng.losses()
+    otasks = OTk.instantiate_tasks(om, tasks, None, lambda: 0.37)
+    o_art, o_b = oracle_artefacts(art, host), {d: to_oracle(b) for d, b in host.items()}
+    for t in tasks:
+        want = otasks[t].loss(o_b, o_art.get(t))[0].item()
+        assert abs(got[t] - want) <= 1e-4 * abs(want), (t, got[t], want)
+    # a pipelined run through the prefetcher: tickets of three inputs in flight, every step gets fresh draws
+    pool = [StepInputs(S.pretrain_step_batches(gen, domains), DEV, eng.dpad) for _ in range(3)]
+    pf = StepPrefetcher(eng, (pool[i % 3] for i in range(12)), gen)
+    seen = []
+    for inp_k, prepared in pf:
+        seen.append(tuple(prepared[0]["node_feat_mask"][domains[0]][:4]))
+        eng.step(inp_k, gen, prepared=prepared)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    assert len(seen) == 12 and len(set(seen)) > 6
+    assert all(np.isfinite(v) for v in eng.losses().values())
