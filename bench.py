@@ -39,6 +39,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the aggregation-kernel leg (used for the PMC passes)")
+    ap.add_argument("--no-cora", action="store_true", help="skip the Cora_NC fine-tune leg (BASELINE.json configs[4]) of the result line")
     ap.add_argument("--rng", choices=["reference", "vectorized", "device"], default=None,
                     help="how the step's augmentation/mask/negative indices are drawn: 'reference' = the exact "
                          "per-graph draw sequence of the reference from the CPU torch.Generator; 'vectorized' = same "
@@ -222,6 +223,73 @@ def gemm_roofline(device, rows: int = 7392):
                     "its prologue (first DMA, ~3 us with the launch gap) and its 15 MB epilogue + end-of-kernel L2 write-back (~5 us)"}
 
 
+def cora_finetune(device, seed: int, steps: int = 200, cpu_budget_s: float = 6.0):
+    """BASELINE.json configs[4]: Cora_NC full-graph fine-tune (2,708 nodes / 5,429 undirected edges / 1,433 features, 256 hidden,
+    5 GIN layers, CE on the 140 training nodes, AdamW) -- one optimisation step = one epoch of the reference
+    (src/finetune/finetune.py:162-179).  Reported beside the headline line: ms per step on the explicit-kernel engine
+    (finetune/engine.py), the encoder GEMM 2,708 x 1,433(->1,440) x 256 against the fp32 MFMA peak, and the CPU oracle's step."""
+    from gnn_pretraining_amd.finetune.engine import NodeClassificationEngine
+    from gnn_pretraining_amd.models import FinetuneGNN
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    g = S.cora_like(gen)
+    model = FinetuneGNN(device, "Cora_NC", "full_finetune")
+    model.train()
+    eng = NodeClassificationEngine(model, g.x, g.edge_index, device, seed=seed)
+    idx = torch.randperm(g.num_nodes, generator=gen)[:140]
+    y = g.y[idx].to(device)
+    idx_d = idx.to(device)
+    for _ in range(20):
+        eng.step(idx_d, y)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(idx_d, y)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    loss = eng.loss()
+    # the encoder GEMM alone (the one large dense product of the step), back-to-back launches between two events
+    A, W, b, out = eng.x, torch.randn(256, eng.dpad, device=device), torch.randn(256, device=device), torch.empty(eng.N, 256, device=device)
+    for _ in range(10):
+        ops.gemm(ops.NT, A, W, b, out)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize(device)
+    ev[0].record()
+    for _ in range(50):
+        ops.gemm(ops.NT, A, W, b, out)
+    ev[1].record()
+    torch.cuda.synchronize(device)
+    gms = ev[0].elapsed_time(ev[1]) / 50
+    flops = 2.0 * eng.N * 256 * eng.d_in                       # algorithmic: the padded columns are zeros
+    out_d = {"workload": "Cora_NC-shaped full-graph fine-tune step (N=2708, E=10858 directed, F=1433, 7 classes, 140 training nodes)",
+             "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 1), "loss_after": round(loss, 4), "steps": steps,
+             "roofline_gemm": {"bound": "mfma", "achieved": round(flops / (gms * 1e-3) / 1e12, 1), "peak": 157.0, "unit": "TFLOP/s",
+                               "frac": round(flops / (gms * 1e-3) / 1e12 / 157.0, 4), "kernel": "gemm_pipe_kernel NT (input encoder 2708 x 1433 -> 256)",
+                               "avg_launch_ms": round(gms, 4), "launches": 50}}
+    # CPU oracle: the same step (oracle model + torch AdamW with the reference's groups) on the host cores
+    from oracle import models as OM
+    from oracle.harness import to_oracle
+    from gnn_pretraining_amd.graph import Batch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    om = OM.FinetuneGNN(torch.device("cpu"), "Cora_NC", "full_finetune")
+    om.train()
+    opt = torch.optim.AdamW(om.param_groups)
+    ob = to_oracle(Batch.from_data_list([g]))
+    times, t_end = [], time.time() + cpu_budget_s
+    while (time.time() < t_end and len(times) < 40) or len(times) < 3:
+        t1 = time.time()
+        lo = torch.nn.functional.cross_entropy(om(ob)[idx], g.y[idx])
+        opt.zero_grad(); lo.backward(); opt.step()
+        times.append(time.time() - t1)
+    torch.set_num_threads(1)
+    times.sort()
+    med = times[len(times) // 2]
+    out_d["cpu_baseline"] = {"value": round(1.0 / med, 2), "unit": "steps/s", "cores": cores, "kind": "port",
+                             "sample": f"{len(times)} steps of the same workload on the torch-only oracle (median {med * 1e3:.1f} ms/step)"}
+    return out_d
+
+
 def cpu_baseline(seed: int, budget_s: float = 20.0):
     """The CPU oracle (a port: the reference itself needs torch_geometric) on this box's host cores."""
     from oracle import models as OM, tasks as OTk, train as OTr
@@ -364,6 +432,10 @@ def main() -> None:
         log(f"roofline {roof['achieved']} GB/s")
         roof_gemm = gemm_roofline(device)
         log(f"gemm {roof_gemm['achieved']} TFLOP/s")
+    cora = None
+    if rank == 0 and world == 1 and not a.no_cora:
+        cora = cora_finetune(device, seed)
+        log(f"cora fine-tune step {cora['ms_per_step']} ms (CPU oracle {cora['cpu_baseline']['value']} steps/s)")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline ...")
         cpu = cpu_baseline(seed)
@@ -382,7 +454,7 @@ def main() -> None:
                        "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                        "devices_visible": torch.cuda.device_count(),
                        "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
-            "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm, "roofline_bwd": ROOFLINE_BWD,
+            "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm, "roofline_bwd": ROOFLINE_BWD, "cora_finetune": cora,
         }
         emit(line)
     if world > 1:

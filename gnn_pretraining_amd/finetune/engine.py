@@ -1,0 +1,238 @@
+"""One full-graph node-classification fine-tune step as an explicit kernel sequence (BASELINE.json configs[4]: Cora_NC).
+
+The reference's epoch on Cora_NC is ONE optimisation step over the whole graph (src/finetune/finetune.py:162-179, batch_size -1):
+`model(data)` = InputEncoder (Linear 1433 -> 256, BN, ReLU, dropout) -> 5 GIN layers on all 2,708 nodes -> Linear 256 -> 7,
+cross-entropy (mean) on the 140 training nodes, `loss.backward()`, `AdamW(model.param_groups).step()`
+(src/models/finetune_model.py:38-64: encoder / head lr 1e-3, backbone 1e-4, AdamW's default weight decay 0.01, no clipping).
+The module path (models/finetune_model.py on autograd Functions) runs that in 3.4 ms, nearly all of it host time in ~200 small
+autograd nodes.  Here the same step is ~60 launches with no autograd and no host synchronisation: the graph's CSR is built once,
+the encoder's K = 1,433 is padded to 1,440 (a multiple of the GEMM's 32-deep K-step; the weight's padded columns stay zero), and
+the optimizer is the pre-training engine's multi-tensor AdamW over one flat buffer.
+
+`FinetuneGNN` stays the owner of the parameters (its tensors become views into the flat buffer, `state_dict()` keys unchanged),
+so checkpoints, evaluation and the reference-shaped loop around it are untouched."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _lib as L, ops
+from ..models.finetune_model import LR_BACKBONE, LR_FINETUNE, FinetuneGNN
+from ..models.gnn import DROPOUT_RATE, GNN_HIDDEN_DIM, GNN_NUM_LAYERS
+
+H = GNN_HIDDEN_DIM
+NT, NN, TN = 0, 1, 2
+ADAMW_WEIGHT_DECAY = 0.01           # torch.optim.AdamW default: the reference passes none (finetune.py:363)
+
+
+def _i32(xs):
+    return (C.c_int32 * len(xs))(*[int(v) for v in xs])
+
+
+def _i64(xs):
+    return (C.c_int64 * len(xs))(*[int(v) for v in xs])
+
+
+class NodeClassificationEngine:
+    def __init__(self, model: FinetuneGNN, x: Tensor, edge_index: Tensor, device, seed: int = 0) -> None:
+        self.model, self.device, self.lib = model, torch.device(device), L.lib()
+        self.seed, self.step_count, self.dropout_p = seed, 0, DROPOUT_RATE
+        dev = self.device
+        self.N, self.d_in = int(x.size(0)), int(x.size(1))
+        self.dpad = (self.d_in + 31) // 32 * 32
+        self.x = torch.zeros(self.N, self.dpad, device=dev)
+        self.x[:, :self.d_in] = x.to(dev)
+        self.csr = ops.csr_build(edge_index.to(dev).contiguous(), self.N)
+        self.classes = int(model.classification_head.mlp[0].weight.size(0))
+        self._flatten()
+        f = lambda *s: torch.empty(*s, device=dev)
+        N, Lr = self.N, GNN_NUM_LAYERS
+        self.z0, self.h = f(N, H), [f(N, H) for _ in range(Lr + 1)]
+        self.a, self.z1, self.r1, self.z2 = [f(N, H) for _ in range(Lr)], [f(N, 2 * H) for _ in range(Lr)], [f(N, 2 * H) for _ in range(Lr)], [f(N, H) for _ in range(Lr)]
+        self.stat = {k: f(Lr, c) for k, c in (("m1", 2 * H), ("s1", 2 * H), ("m2", H), ("s2", H))}
+        self.enc_mean, self.enc_rstd = f(H), f(H)
+        self.logits, self.gA, self.gB, self.ga, self.gW, self.gW2 = f(N, self.classes), f(N, H), f(N, H), f(N, H), f(N, 2 * H), f(N, 2 * H)
+        self.rowdot = f(N)
+        self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
+        self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
+        self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+        self.loss_ws = torch.empty(self.lib.gmp_loss_workspace_bytes(N * H), dtype=torch.uint8, device=dev)
+        self.loss_sum, self.g_scale = torch.zeros(1, device=dev), torch.ones(1, device=dev)
+        self.mt_ws = torch.empty(self.lib.gmp_mt_workspace_bytes(self.K), dtype=torch.uint8, device=dev)
+        self.normsq, self.metrics, self.flags = torch.zeros(1, device=dev), torch.zeros(2, dtype=torch.int32, device=dev), torch.zeros(self.K, dtype=torch.int32, device=dev)
+        self._train_idx: Optional[Tensor] = None
+        self._bn_calls = 0
+
+    # ------------------------------------------------------------------ parameters: one flat buffer, the module's tensors view into it
+    def _flatten(self) -> None:
+        m, dev = self.model, self.device
+        named = [(n, p) for n, p in m.named_parameters()]
+        al4 = lambda v: (v + 3) // 4 * 4
+        self.off: Dict[str, int] = {}
+        self.numel: Dict[str, int] = {}
+        o = 0
+        for n, p in named:
+            cnt = H * self.dpad if n == "input_encoder.linear.weight" else p.numel()      # encoder weight: rows padded to dpad columns
+            self.off[n], self.numel[n] = o, cnt
+            o += al4(cnt)
+        self.P = o
+        self.flat = torch.zeros(self.P, device=dev)
+        for n, p in named:
+            a = self.off[n]
+            if n == "input_encoder.linear.weight":
+                view = self.flat[a:a + H * self.dpad].view(H, self.dpad)
+                view[:, :self.d_in].copy_(p.data)
+                p.data = view[:, :self.d_in]                      # strided view: the padded columns are outside the parameter
+            else:
+                self.flat[a:a + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat[a:a + p.numel()].view_as(p)
+        self.names = [n for n, _ in named]
+        self.K = len(self.names)
+        self.grad = torch.zeros(1, self.P, device=dev)            # [tasks = 1, P]
+        self.final_grad = torch.zeros(self.P, device=dev)
+        self.exp_avg, self.exp_avg_sq = torch.zeros(self.P, device=dev), torch.zeros(self.P, device=dev)
+        self.t_off = torch.tensor([self.off[n] for n in self.names], dtype=torch.int64, device=dev)
+        self.t_len = torch.tensor([self.numel[n] for n in self.names], dtype=torch.int32, device=dev)
+        trainable = {n: p.requires_grad for n, p in named}
+        has = torch.zeros(self.K, 8, dtype=torch.uint8)
+        lr = torch.zeros(self.K)
+        for k, n in enumerate(self.names):
+            has[k, 0] = 1 if trainable[n] else 0
+            lr[k] = LR_BACKBONE if n.startswith("gnn_backbone.") else LR_FINETUNE
+        self.has, self.lr = has.to(dev), lr.to(dev)
+        self.wd = torch.full((self.K,), ADAMW_WEIGHT_DECAY, device=dev)
+        self.steps = torch.zeros(self.K, device=dev)
+
+    def _P(self, n: str) -> int:
+        return self.flat.data_ptr() + 4 * self.off[n]
+
+    def _G(self, n: str) -> int:
+        return self.off[n]
+
+    def _chk(self, rc: int, what: str) -> None:
+        if rc:
+            L.check(rc, what)
+
+    def _cfg(self, relu: bool, dropout: bool, site: int) -> L.BnConfig:
+        p = self.dropout_p if (dropout and self.model.training) else 0.0
+        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site)
+
+    def _gemm(self, st, mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc):
+        self._chk(self.lib.gmp_gemm_f32(mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, 1.0, 0, 0, None, 0, st), "gemm")
+
+    def _wgrad(self, st, G, X, w_name: str, b_name: str, M_tn: int, N_out: int, ldx: int):
+        """dW = G^T X and db = colsum(G) over all rows (one group), straight into the gradient buffer."""
+        g = self.grad.data_ptr()
+        self._chk(self.lib.gmp_gemm_f32_grouped(TN, G, X, None, g, 1, _i32([0, self.N]), None, None, _i64([self._G(w_name)]), g, _i64([self._G(b_name)]),
+                                                M_tn, N_out, 0, M_tn, ldx, N_out, 1.0, 0, 0, self.gemm_ws.data_ptr(), self.gemm_ws.numel(), st), "wgrad")
+
+    # ------------------------------------------------------------------ forward (finetune_model.py:68-80, message passing on the full graph)
+    def forward(self) -> Tensor:
+        lib, N, P, c = self.lib, self.N, self._P, self.csr
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        enc, sp = self.model.input_encoder, self.seg_ptr.data_ptr()
+        self._gemm(st, NT, self.x.data_ptr(), P("input_encoder.linear.weight"), P("input_encoder.linear.bias"), self.z0.data_ptr(), N, H, self.dpad,
+                   self.dpad, self.dpad, H)
+        cfg = self._cfg(True, True, 1)
+        self._chk(lib.gmp_bn_fwd(self.z0.data_ptr(), None, sp, None, 1, N, N, H, P("input_encoder.batch_norm.weight"), P("input_encoder.batch_norm.bias"),
+                                 enc.batch_norm.running_mean.data_ptr(), enc.batch_norm.running_var.data_ptr(), self.enc_mean.data_ptr(),
+                                 self.enc_rstd.data_ptr(), self.h[0].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn encoder")
+        for l in range(GNN_NUM_LAYERS):
+            pre, layer = f"gnn_backbone.layers.{l}.", self.model.gnn_backbone.layers[l]
+            self._chk(lib.gmp_gin_aggregate_fwd(self.h[l].data_ptr(), c.rowptr.data_ptr(), c.col.data_ptr(), P(pre + "gin_conv.eps"), self.a[l].data_ptr(), N, H, st), "aggregate")
+            self._gemm(st, NT, self.a[l].data_ptr(), P(pre + "gin_conv.nn.0.weight"), P(pre + "gin_conv.nn.0.bias"), self.z1[l].data_ptr(), N, 2 * H, H, H, H, 2 * H)
+            bn1, cfg = layer.gin_conv.nn[1], self._cfg(True, False, 0)
+            self._chk(lib.gmp_bn_fwd(self.z1[l].data_ptr(), None, sp, None, 1, N, N, 2 * H, P(pre + "gin_conv.nn.1.weight"), P(pre + "gin_conv.nn.1.bias"),
+                                     bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), self.stat["m1"][l].data_ptr(), self.stat["s1"][l].data_ptr(),
+                                     self.r1[l].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1")
+            self._gemm(st, NT, self.r1[l].data_ptr(), P(pre + "gin_conv.nn.3.weight"), P(pre + "gin_conv.nn.3.bias"), self.z2[l].data_ptr(), N, H, 2 * H, 2 * H, 2 * H, H)
+            bn2, cfg = layer.batch_norm, self._cfg(True, True, 10 + l)
+            self._chk(lib.gmp_bn_fwd(self.z2[l].data_ptr(), self.h[l].data_ptr(), sp, None, 1, N, N, H, P(pre + "batch_norm.weight"), P(pre + "batch_norm.bias"),
+                                     bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), self.stat["m2"][l].data_ptr(), self.stat["s2"][l].data_ptr(),
+                                     self.h[l + 1].data_ptr(), C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2")
+        self._gemm(st, NT, self.h[GNN_NUM_LAYERS].data_ptr(), P("classification_head.mlp.0.weight"), P("classification_head.mlp.0.bias"), self.logits.data_ptr(),
+                   N, self.classes, H, H, H, self.classes)
+        if self.model.training:
+            self._bn_calls += 1             # num_batches_tracked only matters for a saved state_dict (momentum is fixed): flush_counters()
+        return self.logits
+
+    def flush_counters(self) -> None:
+        if self._bn_calls:
+            enc = self.model.input_encoder
+            for bn in [enc.batch_norm] + [b for l in self.model.gnn_backbone.layers for b in (l.gin_conv.nn[1], l.batch_norm)]:
+                bn.num_batches_tracked += self._bn_calls
+            self._bn_calls = 0
+
+    # ------------------------------------------------------------------ one optimisation step (finetune.py:162-179 + 318-320)
+    def step(self, node_indices: Tensor, targets: Tensor, apply_update: bool = True) -> None:
+        """loss = cross_entropy(model(data)[node_indices], targets) (mean); backward; AdamW.  Nothing is read back: loss()."""
+        lib, N, P, c, Cn = self.lib, self.N, self._P, self.csr, self.classes
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.forward()
+        M = int(node_indices.numel())
+        if self._train_idx is None or self._train_idx.numel() != M:
+            f = lambda *s: torch.empty(*s, device=self.device)
+            self._rows_logits, self._rows_g, self._rows_h = f(M, Cn), f(M, Cn), f(M, H)
+            self._rows_gh = f(M, H)
+        self._train_idx, self.num_targets = node_indices, M
+        self.g_scale.fill_(1.0 / M)
+        idx, tgt, g = node_indices.data_ptr(), targets.data_ptr(), self.grad.data_ptr()
+        hL = self.h[GNN_NUM_LAYERS]
+        self._chk(lib.gmp_row_gather(self.logits.data_ptr(), idx, None, self._rows_logits.data_ptr(), M, N, Cn, st), "logit rows")
+        self._chk(lib.gmp_cross_entropy_sum_fwd(self._rows_logits.data_ptr(), tgt, M, Cn, self.loss_sum.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "ce")
+        self._chk(lib.gmp_cross_entropy_sum_bwd(self._rows_logits.data_ptr(), tgt, M, Cn, self.g_scale.data_ptr(), self._rows_g.data_ptr(), st), "ce bwd")
+        # head: dW = g^T h[idx], db = colsum(g), g_h[idx] = g W  (only the M training rows carry a gradient)
+        self._chk(lib.gmp_row_gather(hL.data_ptr(), idx, None, self._rows_h.data_ptr(), M, N, H, st), "h rows")
+        self._chk(lib.gmp_gemm_f32_grouped(TN, self._rows_g.data_ptr(), self._rows_h.data_ptr(), None, g, 1, _i32([0, M]), None, None,
+                                           _i64([self._G("classification_head.mlp.0.weight")]), g, _i64([self._G("classification_head.mlp.0.bias")]),
+                                           Cn, H, 0, Cn, H, H, 1.0, 0, 0, None, 0, st), "head wgrad")
+        self._gemm(st, NN, self._rows_g.data_ptr(), P("classification_head.mlp.0.weight"), None, self._rows_gh.data_ptr(), M, H, Cn, Cn, H, H)
+        gcur, gu, ga = self.gA, self.gB, self.ga
+        gcur.zero_()
+        self._chk(lib.gmp_row_fill(gcur.data_ptr(), idx, self._rows_gh.data_ptr(), M, N, H, 0, st), "scatter g_h")
+        sp, one = self.seg_ptr.data_ptr(), _i32([0, 1])
+        for l in reversed(range(GNN_NUM_LAYERS)):
+            pre, layer = f"gnn_backbone.layers.{l}.", self.model.gnn_backbone.layers[l]
+            bn2, cfg = layer.batch_norm, self._cfg(True, True, 10 + l)
+            self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z2[l].data_ptr(), self.h[l].data_ptr(), sp, None, 1, N, N, H, P(pre + "batch_norm.weight"),
+                                     P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), self.stat["m2"][l].data_ptr(),
+                                     self.stat["s2"][l].data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G(pre + "batch_norm.weight")]),
+                                     _i64([self._G(pre + "batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2 bwd")
+            self._wgrad(st, gu.data_ptr(), self.r1[l].data_ptr(), pre + "gin_conv.nn.3.weight", pre + "gin_conv.nn.3.bias", H, 2 * H, 2 * H)
+            self._gemm(st, NN, gu.data_ptr(), P(pre + "gin_conv.nn.3.weight"), None, self.gW.data_ptr(), N, 2 * H, H, H, 2 * H, 2 * H)
+            bn1, cfg = layer.gin_conv.nn[1], self._cfg(True, False, 0)
+            self._chk(lib.gmp_bn_bwd(self.gW.data_ptr(), self.z1[l].data_ptr(), None, sp, None, 1, N, N, 2 * H, P(pre + "gin_conv.nn.1.weight"),
+                                     P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), self.stat["m1"][l].data_ptr(),
+                                     self.stat["s1"][l].data_ptr(), self.gW2.data_ptr(), g, g, one, _i64([self._G(pre + "gin_conv.nn.1.weight")]),
+                                     _i64([self._G(pre + "gin_conv.nn.1.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1 bwd")
+            self._wgrad(st, self.gW2.data_ptr(), self.a[l].data_ptr(), pre + "gin_conv.nn.0.weight", pre + "gin_conv.nn.0.bias", 2 * H, H, H)
+            self._gemm(st, NN, self.gW2.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
+            self._chk(lib.gmp_gin_aggregate_bwd_ex(ga.data_ptr(), c.rowptr_t.data_ptr(), c.col_t.data_ptr(), P(pre + "gin_conv.eps"), self.h[l].data_ptr(),
+                                                   gu.data_ptr(), gcur.data_ptr(), self.rowdot.data_ptr(), N, H, st), "aggregate bwd")
+            self._chk(lib.gmp_group_sum_1d(self.rowdot.data_ptr(), 1, _i32([0, N]), _i64([self._G(pre + "gin_conv.eps")]), g, st), "eps grad")
+        enc, cfg = self.model.input_encoder, self._cfg(True, True, 1)
+        self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z0.data_ptr(), None, sp, None, 1, N, N, H, P("input_encoder.batch_norm.weight"),
+                                 P("input_encoder.batch_norm.bias"), enc.batch_norm.running_mean.data_ptr(), enc.batch_norm.running_var.data_ptr(),
+                                 self.enc_mean.data_ptr(), self.enc_rstd.data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G("input_encoder.batch_norm.weight")]),
+                                 _i64([self._G("input_encoder.batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn encoder bwd")
+        self._wgrad(st, gu.data_ptr(), self.x.data_ptr(), "input_encoder.linear.weight", "input_encoder.linear.bias", H, self.dpad, self.dpad)
+        # AdamW over the flat buffer (the pre-training engine's multi-tensor kernels with one task: no projection, no clipping)
+        self._chk(lib.gmp_mt_pcgrad_clip_adamw(g, self.P, 1, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(), _i32([0]), 1, 0, -1,
+                                               self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                               self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, 0.0,
+                                               self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(),
+                                               self.mt_ws.data_ptr(), self.mt_ws.numel(), int(apply_update), st), "adamw")
+        self.step_count += 1
+
+    def loss(self) -> float:
+        return float(self.loss_sum.item()) / max(self.num_targets, 1)
+
+    def gradient(self, name: str) -> Tensor:
+        o = self.off[name]
+        if name == "input_encoder.linear.weight":
+            return self.final_grad[o:o + H * self.dpad].view(H, self.dpad)[:, :self.d_in]
+        p = dict(self.model.named_parameters())[name]
+        return self.final_grad[o:o + p.numel()].view_as(p)

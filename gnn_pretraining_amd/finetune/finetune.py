@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import time
 from dataclasses import dataclass
 from pathlib import Path
@@ -197,6 +198,29 @@ def run_training(model: FinetuneGNN, optimizer, train_loader, device, epoch: int
                                                 probabilities, t0, model), global_step[0])
 
 
+def run_training_node_engine(engine, train_loader, device, epoch: int, global_step: List[int], cfg: FinetuneConfig, logger: JsonlLogger) -> None:
+    """run_training for the full-graph node-classification domains on the explicit-kernel step (finetune/engine.py): one
+    engine.step per batch -- forward on all nodes, CE on the batch's nodes, backward, AdamW with the reference's parameter groups --
+    with no autograd graph and nothing read back unless a log is being written."""
+    model = engine.model
+    model.train()
+    for (_, node_indices, targets) in train_loader:
+        t0 = time.time()
+        global_step[0] += 1
+        idx, tgt = node_indices.to(device), targets.to(device)
+        engine.step(idx, tgt)
+        if logger.f:
+            lg = engine._rows_logits.detach()
+            loss = torch.tensor(engine.loss())
+            m = compute_batch_metrics(cfg.domain_name, tgt, lg.argmax(dim=1), torch.softmax(lg, dim=1), loss, "train")
+            for pg in model.param_groups:
+                m[f'train/lr/{pg["name"]}'] = pg["lr"]
+            m["train/gradients/model_grad_norm"] = float(engine.normsq.sqrt())
+            m["train/progress/epoch"], m["train/progress/step"] = epoch, global_step[0]
+            m["train/system/time_per_step"] = time.time() - t0
+            logger.log(m, global_step[0])
+
+
 def evaluate(model: FinetuneGNN, loader, device, cfg: FinetuneConfig, prefix: str, miner, train_edges) -> List[Dict[str, float]]:
     return [compute_loss_and_metrics(model, b, device, cfg.task_type, cfg.domain_name, prefix, miner, train_edges) for b in loader]
 
@@ -231,8 +255,17 @@ def finetune(cfg: FinetuneConfig, epochs: Optional[int] = None, device: Optional
     torch.save({"epoch": 0, "model_state_dict": model.state_dict(), "val_metrics": {}}, path)
     key = "val/auc" if cfg.task_type == "link_prediction" else "val/accuracy"
     best, stale, global_step, epoch = -float("inf"), 0, [0], 0
+    node_engine = None
+    if cfg.task_type == "node_classification" and os.environ.get("GMP_FINETUNE_ENGINE", "1") != "0":
+        from .engine import NodeClassificationEngine
+        data = train_loader.dataset.data
+        node_engine = NodeClassificationEngine(model, data.x, data.edge_index, dev, seed=cfg.seed)
     for epoch in range(1, (epochs or cfg.epochs) + 1):
-        run_training(model, optimizer, train_loader, dev, epoch, global_step, cfg, miner, logger)
+        if node_engine is not None:
+            run_training_node_engine(node_engine, train_loader, dev, epoch, global_step, cfg, logger)
+            node_engine.flush_counters()
+        else:
+            run_training(model, optimizer, train_loader, dev, epoch, global_step, cfg, miner, logger)
         edges = _train_edges(train_loader, dev)
         val = compute_validation_metrics(evaluate(model, val_loader, dev, cfg, "val", miner, edges), epoch)
         if val[key] > best:

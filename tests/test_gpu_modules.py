@@ -4,6 +4,8 @@ same state_dict, same inputs, same RNG artefacts; train-mode BatchNorm, dropout 
 fp32 tolerance 1e-4 relative for outputs/losses (north_star); gradient tolerance: parity_util.assert_grad_close."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -288,3 +290,58 @@ def test_finetune_link_prediction_train_step_with_mined_negatives():
 def ops_matrix(emb, edges):
     from gnn_pretraining_amd import ops
     return ops.hard_negative_topk(emb.contiguous(), edges, 1, return_matrix=True)[1].cpu()
+
+
+def test_finetune_node_classification_engine_matches_the_oracle_step():
+    """BASELINE.json configs[4]: one Cora_NC-shaped full-graph fine-tune step (2,708 x 1,433, 5 GIN layers, CE on 140 nodes,
+    AdamW with the reference's parameter groups -- finetune.py:162-179, finetune_model.py:38-64) on the explicit-kernel engine
+    (finetune/engine.py) against the oracle model + torch.optim.AdamW: loss, every gradient, every parameter after the update,
+    running statistics; the engine's parameters stay views of the module (state_dict keys and values)."""
+    from gnn_pretraining_amd.finetune.engine import NodeClassificationEngine
+    from gnn_pretraining_amd.graph import Batch
+    gen = torch.Generator().manual_seed(33)
+    torch.manual_seed(33)
+    om = OM.FinetuneGNN(torch.device("cpu"), "Cora_NC", "full_finetune")
+    hm = FinetuneGNN(torch.device("cpu"), "Cora_NC", "full_finetune")
+    copy_state(hm, om); hm.device = DEV; hm.to(DEV)
+    set_dropout(om, 0.0)
+    om.train(); hm.train()
+    c = S.cora_like(gen)
+    idx = torch.randperm(c.num_nodes, generator=gen)[:140]
+    eng = NodeClassificationEngine(hm, c.x, c.edge_index, DEV, seed=3)
+    eng.dropout_p = 0.0
+    keys_before = list(hm.state_dict().keys())
+    # oracle step
+    oopt = torch.optim.AdamW(om.param_groups)
+    for g in oopt.param_groups:
+        g["lr"] *= 100                                   # visible update (lr 1e-4 moves weights by 1e-4 x Adam's unit step)
+    eng.lr.mul_(100)
+    before = {k: v.clone() for k, v in om.state_dict().items()}
+    lo = torch.nn.functional.cross_entropy(om(to_oracle(Batch.from_data_list([c])))[idx], c.y[idx])
+    oopt.zero_grad(); lo.backward(); oopt.step()
+    eng.step(idx.to(DEV), c.y[idx].to(DEV))
+    assert abs(eng.loss() - lo.item()) <= 1e-4 * abs(lo.item())
+    og = dict(om.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in og.values())
+    for n, p in og.items():
+        assert_grad_close(eng.gradient(n), p.grad, gmax, f"grad {n}")
+    eng.flush_counters()
+    after_o, after_h = om.state_dict(), hm.state_dict()
+    assert list(after_h.keys()) == keys_before
+    num = den = 0.0
+    for k, v in after_o.items():
+        if "running_" in k:
+            assert_close(after_h[k], v, 1e-4, f"buffer {k}")
+        elif k.endswith("num_batches_tracked"):
+            assert int(after_h[k]) == int(v)
+        elif k.endswith("linear.bias") or k.endswith("gin_conv.nn.0.bias") or k.endswith("gin_conv.nn.3.bias"):
+            # a bias in front of a train-mode BatchNorm has an analytically ZERO gradient: both sides hold rounding noise, and Adam's
+            # first step turns noise into +-lr -- nothing to compare beyond "it moved by at most one step"
+            assert (after_h[k].cpu() - before[k]).abs().max().item() <= 1.01 * 100 * 1e-3
+        else:
+            num += ((after_h[k].cpu() - v).double() ** 2).sum().item()
+            den += ((v - before[k]).double() ** 2).sum().item()
+    assert (num / den) ** 0.5 <= 2e-2, f"relative update error {(num / den) ** 0.5:.3e}"
+    # a second step runs from the updated state (moments, step counters) and keeps the loss finite
+    eng.step(idx.to(DEV), c.y[idx].to(DEV))
+    assert np.isfinite(eng.loss())
