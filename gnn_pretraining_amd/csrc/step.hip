@@ -360,8 +360,12 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (d.task[ti].kind == GMP_TASK_LP) lp_task = ti;
     if (lp_task >= 0) {
         const gmp_task_desc& t = d.task[lp_task];
-        GMP_TRY(gmp_csr_build(t.lp_edges, N, t.lp_K, d.lp_csr[0], d.lp_csr[1], d.lp_csr[2], d.lp_csr[3], d.lp_csr[4], d.lp_csr[5], d.lp_csr_status,
-                              d.lp_csr_ws, d.lp_csr_ws_bytes, aux_));
+        if (d.lp_S > 0)
+            GMP_TRY(gmp_csr_build_segmented(t.lp_edges, d.lp_rows_end, t.lp_K, d.lp_seg_ptr, d.lp_seg_eptr, d.lp_S, d.lp_max_seg_rows, d.lp_max_seg_edges,
+                                            d.lp_csr[0], d.lp_csr[1], d.lp_csr[2], d.lp_csr[3], d.lp_csr[4], d.lp_csr[5], d.lp_csr_status, aux_));
+        else
+            GMP_TRY(gmp_csr_build(t.lp_edges, N, t.lp_K, d.lp_csr[0], d.lp_csr[1], d.lp_csr[2], d.lp_csr[3], d.lp_csr[4], d.lp_csr[5], d.lp_csr_status,
+                                  d.lp_csr_ws, d.lp_csr_ws_bytes, aux_));
     }
     (void)hipEventRecord(ev[2], aux);
 

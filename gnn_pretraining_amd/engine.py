@@ -799,6 +799,12 @@ class StepEngine:
                     a64["lp_edges"] = e
                     p.lp_labels, p.lp_K = lab, e.shape[1]
                     sizes[t] = e.shape[1]
+                    # block diagonal by domain: the decoder CSR is built one workgroup per (domain, orientation)
+                    a32["lp_seg_ptr"] = np.asarray(r0s + [seg_ptr[-1]])
+                    a32["lp_seg_eptr"] = np.concatenate([[0], np.cumsum([a + b for a, b in npos])])
+                    p.lp_S, p.lp_rows_end = len(r0s), seg_ptr[-1]
+                    p.lp_max_rows = int(np.diff(a32["lp_seg_ptr"]).max())
+                    p.lp_max_edges = int(np.diff(a32["lp_seg_eptr"]).max())
                 else:
                     starts, rows, labels = [], [0], []
                     for di, (d, r0) in enumerate(zip(D, r0s)):
@@ -1058,6 +1064,10 @@ class StepEngine:
             a = self._tg_cache[name] = _i64([t * self.P + self.off[name] for t in range(self.T)])
         return a
 
+    @staticmethod
+    def _lp_segmented(p: StepPlan) -> bool:
+        return p.lp_S > 0 and p.lp_max_rows <= SEG_CSR_MAX_ROWS and p.lp_max_edges <= SEG_CSR_MAX_EDGES
+
     def _forward(self, p: StepPlan, inp: StepInputs) -> None:
         lib, st, N, D, P = self.lib, self._st(), p.N, self.domains, self._P
         c = self.csr
@@ -1078,9 +1088,14 @@ class StepEngine:
             ev_csr = torch.cuda.Event(); ev_csr.record(self.aux_stream)
             if "link_pred" in self.tasks:
                 lc = self.lp_csr
-                self._chk(lib.gmp_csr_build(p.d64["lp_edges"], N, p.lp_K, lc[0].data_ptr(), lc[1].data_ptr(), lc[2].data_ptr(), lc[3].data_ptr(),
-                                            lc[4].data_ptr(), lc[5].data_ptr(), self.lp_csr_status.data_ptr(), self.lp_csr_ws.data_ptr(),
-                                            self.lp_csr_ws.numel(), ast), "lp csr")
+                if self._lp_segmented(p):
+                    self._chk(lib.gmp_csr_build_segmented(p.d64["lp_edges"], p.lp_rows_end, p.lp_K, p.d32["lp_seg_ptr"], p.d32["lp_seg_eptr"], p.lp_S,
+                                                          p.lp_max_rows, p.lp_max_edges, lc[0].data_ptr(), lc[1].data_ptr(), lc[2].data_ptr(),
+                                                          lc[3].data_ptr(), lc[4].data_ptr(), lc[5].data_ptr(), self.lp_csr_status.data_ptr(), ast), "lp csr (segmented)")
+                else:
+                    self._chk(lib.gmp_csr_build(p.d64["lp_edges"], N, p.lp_K, lc[0].data_ptr(), lc[1].data_ptr(), lc[2].data_ptr(), lc[3].data_ptr(),
+                                                lc[4].data_ptr(), lc[5].data_ptr(), self.lp_csr_status.data_ptr(), self.lp_csr_ws.data_ptr(),
+                                                self.lp_csr_ws.numel(), ast), "lp csr")
             p.ev_lpcsr = torch.cuda.Event(); p.ev_lpcsr.record(self.aux_stream)
         w_off = [self.off[f"input_encoders.{d}.linear.weight"] for d in D]
         b_off = [self.off[f"input_encoders.{d}.linear.bias"] for d in D]
@@ -1733,6 +1748,11 @@ class StepEngine:
                 td.da_labels, td.da_lambda, td.da_dropout = p.d64["da_labels"], float(self.grl_lambda), float(self.da_dropout)
             if t == "link_pred":
                 td.lp_K, td.lp_edges = p.lp_K, p.d64["lp_edges"]
+                if self._lp_segmented(p):
+                    d.lp_seg_ptr, d.lp_seg_eptr, d.lp_S = p.d32["lp_seg_ptr"], p.d32["lp_seg_eptr"], p.lp_S
+                    d.lp_max_seg_rows, d.lp_max_seg_edges, d.lp_rows_end = p.lp_max_rows, p.lp_max_edges, p.lp_rows_end
+                else:
+                    d.lp_S = 0
         return d
 
     def _encoder_groups(self, p: StepPlan):

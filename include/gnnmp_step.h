@@ -100,6 +100,11 @@ typedef struct {
     /* graph structure scratch */
     int32_t* csr[6]; int32_t* csr_status; void* csr_ws; size_t csr_ws_bytes;
     int32_t* lp_csr[6]; int32_t* lp_csr_status; void* lp_csr_ws; size_t lp_csr_ws_bytes;
+    /* the link-prediction decoder's edge list is block diagonal too (one block per domain: positives + negatives of that domain's
+       batch, rows of the task's own segments): lp_seg_ptr / lp_seg_eptr (device int32 [lp_S + 1]) let its CSR be built by one
+       workgroup per (domain, orientation) -- gmp_csr_build_segmented over rows [0, lp_rows_end) -- instead of one workgroup for all
+       ~30 k edges (0.49 ms).  lp_S = 0: whole-batch build. */
+    const int32_t *lp_seg_ptr, *lp_seg_eptr; int32_t lp_S; int64_t lp_max_seg_rows, lp_max_seg_edges, lp_rows_end;
     /* parameters and per-task gradients */
     float* flat; int64_t P; float* task_grads;
     /* encoders */
