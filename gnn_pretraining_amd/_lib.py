@@ -98,6 +98,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_bce_sum_fwd": (C.c_int, [p, p, i64, p, p, sz, p]),
     "gmp_bce_sum_bwd": (C.c_int, [p, p, p, p, i64, p]),
     "gmp_sigmoid_bce_sum_fwd_bwd": (C.c_int, [p, p, i64, p, p, p, p, p, sz, p]),
+    "gmp_sigmoid_bce_signed_sum_fwd_bwd": (C.c_int, [p, p, i64, p, p, p, p, p, sz, p]),
     "gmp_cross_entropy_sum_fwd": (C.c_int, [p, p, i64, i32, p, p, sz, p]),
     "gmp_cross_entropy_sum_bwd": (C.c_int, [p, p, i64, i32, p, p, p]),
     "gmp_row_fill": (C.c_int, [p, p, p, i64, i64, i32, i32, p]),

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(T) void bce_bwd_kernel(const float* __restrict__ p,
 
 // sigmoid -> BCE(sum) -> d/dp -> d/dx in one pass (the link-prediction scorer's tail, heads.py:67 + tasks.py:120): the
 // arithmetic of sigmoid_kernel, bce_part_kernel, bce_bwd_kernel and sigmoid_bwd_kernel in that order, element by element,
-// so the numbers are those of the four separate launches
+// so the numbers are those of the four separate launches.  SIGNED: y holds +w for a positive pair and -w for a negative one
+// (w = how many times the pair stands in the reference's list); loss term and gradient are scaled by w (exact for w = 1).
+template <bool SIGNED>
 __global__ __launch_bounds__(T) void sigmoid_bce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gs,
                                                         float* __restrict__ p_out, float* __restrict__ gx, int64_t n, float* part) {
     const float g = gs[0];
@@ -81,9 +83,10 @@ __global__ __launch_bounds__(T) void sigmoid_bce_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < n; i += (int64_t)gridDim.x * T) {
         const float p = 1.f / (1.f + expf(-x[i]));
         const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(log1pf(-p), -100.f);
-        s -= y[i] * lp + (1.f - y[i]) * lq;
-        const float gp = g * (p - y[i]) / fmaxf((1.f - p) * p, 1e-12f);
-        gx[i] = gp * p * (1.f - p);
+        const float yi = SIGNED ? (y[i] > 0.f ? 1.f : 0.f) : y[i], w = SIGNED ? fabsf(y[i]) : 1.f;
+        s -= w * (yi * lp + (1.f - yi) * lq);
+        const float gp = g * (p - yi) / fmaxf((1.f - p) * p, 1e-12f);
+        gx[i] = w * (gp * p * (1.f - p));
         if (p_out) p_out[i] = p;
     }
     block_sum_store(s, part);
@@ -180,15 +183,24 @@ extern "C" int gmp_bce_sum_bwd(const float* p, const float* labels, const float*
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(parts_for(n)), dim3(T), 0, st, p, labels, g_scale, g_p, n);
     return gmp::check_launch("bce_bwd_kernel");
 }
-extern "C" int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, int64_t n, const float* g_scale, float* loss, float* p_out,
-                                          float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+static int sigmoid_bce_launch(bool signed_w, const float* x, const float* labels, int64_t n, const float* g_scale, float* loss, float* p_out,
+                              float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
     GMP_CHECK_N("sigmoid_bce_sum_fwd_bwd")
     if (!loss || !g_scale || !ws || ws_bytes < MAX_PARTS * sizeof(float) || (n > 0 && (!x || !labels || !g_x)))
         return gmp::fail(GMP_ERR_ARG, "sigmoid_bce_sum_fwd_bwd: bad argument");
     const int parts = parts_for(n);
-    hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(parts), dim3(T), 0, st, x, labels, g_scale, p_out, g_x, n, (float*)ws);
+    if (signed_w) hipLaunchKernelGGL(sigmoid_bce_kernel<true>, dim3(parts), dim3(T), 0, st, x, labels, g_scale, p_out, g_x, n, (float*)ws);
+    else hipLaunchKernelGGL(sigmoid_bce_kernel<false>, dim3(parts), dim3(T), 0, st, x, labels, g_scale, p_out, g_x, n, (float*)ws);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(T), 0, st, (const float*)ws, parts, loss);
     return gmp::check_launch("sigmoid_bce kernels");
+}
+extern "C" int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, int64_t n, const float* g_scale, float* loss, float* p_out,
+                                          float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    return sigmoid_bce_launch(false, x, labels, n, g_scale, loss, p_out, g_x, ws, ws_bytes, stream);
+}
+extern "C" int gmp_sigmoid_bce_signed_sum_fwd_bwd(const float* x, const float* signed_weight, int64_t n, const float* g_scale, float* loss,
+                                                 float* p_out, float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    return sigmoid_bce_launch(true, x, signed_weight, n, g_scale, loss, p_out, g_x, ws, ws_bytes, stream);
 }
 extern "C" int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t M, int C, float* loss, void* ws,
                                          size_t ws_bytes, gmp_stream_t stream) {

@@ -174,7 +174,7 @@ int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1
             float* ld1 = drop(d, t.lp_y1, t.lp_d1, K * H, t.lp_site, st, &rc);
             GMP_TRY(rc);
             GMP_TRY(gemm(GMP_GEMM_NT, ld1, w3, b3, t.lp_y2, K, 1, H, H, H, 1, false, st));
-            GMP_TRY(gmp_sigmoid_bce_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
+            GMP_TRY(gmp_sigmoid_bce_signed_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
             *d1_out = ld1;
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy2, w3, nullptr, t.lp_gy1, K, H, 1, 1, H, H, false, st));
             GMP_TRY(gmp_relu_dropout_bwd(t.lp_gy1, t.lp_y1, t.lp_gy1, K * H, d.training ? d.dropout_p : 0.f, d.seed, t.lp_site, st));

@@ -16,7 +16,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -314,6 +316,50 @@ std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor e
     return out;
 }
 
+// The link-prediction scorer's features [hs+hd, hs*hd, |hs-hd|] (src/models/heads.py:57-61) are symmetric in (src, dst), so the
+// ordered pairs (i, j) and (j, i) of one label score identically: the engine scores each unordered pair once and carries its
+// multiplicity as a weight.  pos / neg: [2, E] local node ids of ONE domain batch (n nodes); returns pairs [2, K'] (min, max) +
+// offset, in first-occurrence order (positives first), and signed multiplicities (+count for positives, -count for negatives).
+std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, int64_t n, int64_t offset) {
+    for (const at::Tensor* t : {&pos, &neg})
+        TORCH_CHECK(t->dim() == 2 && t->size(0) == 2 && t->scalar_type() == at::kLong && t->is_contiguous() && t->device().is_cpu(),
+                    "hostdraw: pairs must be contiguous CPU int64 [2, E]");
+    TORCH_CHECK(n >= 0, "hostdraw: negative node count");
+    std::vector<int64_t> a_out, b_out;
+    std::vector<float> w_out;
+    {
+        pybind11::gil_scoped_release nogil;
+        const bool dense = n <= 4096;
+        std::vector<uint16_t> count(dense ? (size_t)(n * n) : 0, 0);
+        std::unordered_map<int64_t, int32_t> sparse;
+        a_out.reserve((size_t)(pos.size(1) + neg.size(1)) / 2 + 16);
+        b_out.reserve(a_out.capacity()); w_out.reserve(a_out.capacity());
+        for (int g = 0; g < 2; ++g) {
+            const at::Tensor& t = g ? neg : pos;
+            const int64_t E = t.size(1);
+            const int64_t *s = t.data_ptr<int64_t>(), *d = s + E;
+            const float sign = g ? -1.f : 1.f;
+            for (int64_t e = 0; e < E; ++e) {
+                const int64_t a = std::min(s[e], d[e]), b = std::max(s[e], d[e]);
+                TORCH_CHECK(a >= 0 && b < n, "hostdraw: pair endpoint outside the domain batch");
+                if (dense) { TORCH_CHECK(count[(size_t)(a * n + b)] < 65535, "hostdraw: pair multiplicity overflow"); ++count[(size_t)(a * n + b)]; }
+                else ++sparse[a * n + b];
+            }
+            for (int64_t e = 0; e < E; ++e) {
+                const int64_t a = std::min(s[e], d[e]), b = std::max(s[e], d[e]);
+                int64_t c;
+                if (dense) { c = count[(size_t)(a * n + b)]; count[(size_t)(a * n + b)] = 0; }
+                else { auto it = sparse.find(a * n + b); c = it->second; it->second = 0; }
+                if (c) { a_out.push_back(a + offset); b_out.push_back(b + offset); w_out.push_back(sign * (float)c); }
+            }
+            sparse.clear();
+        }
+    }
+    at::Tensor w = at::empty({(int64_t)w_out.size()}, at::kFloat);
+    if (!w_out.empty()) std::memcpy(w.data_ptr<float>(), w_out.data(), w_out.size() * sizeof(float));
+    return {to_tensor2(a_out, b_out), w};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("mask_indices", &mask_indices, "per-graph randperm(n)[:max(1, int(.15 n))] + offset for n >= 3");
     pybind11::class_<PyRandom>(m, "PyRandom", "CPython-compatible MT19937 stream (random.getstate()[1] words) for PyG's negative sampler")
@@ -321,5 +367,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("setstate", &PyRandom::setstate)
         .def("getstate", &PyRandom::getstate)
         .def("negative_edges", &PyRandom::negative_edges, "batched_negative_sampling(to_undirected(pos), batch, num_neg_samples=E) of a domain batch");
+    m.def("merge_mirrored_pairs", &merge_mirrored_pairs, "unordered pairs + signed multiplicities of a domain's positive and negative pairs");
     m.def("draw_views", &draw_views, "two augmented views of every graph of a batch, as index arrays");
 }

@@ -160,6 +160,24 @@ def L_view_sizes(ptr_host):
 _HOSTDRAW, _HOSTDRAW_TRIED = None, False
 
 
+def merge_mirrored_pairs(pos: torch.Tensor, neg: np.ndarray, n: int, offset: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Unordered pairs [2, K'] (+offset) and signed multiplicities (+w positive, -w negative) of one domain's scored pairs: the
+    LP scorer's features (heads.py:57-61) are symmetric in (src, dst), so (i, j) and (j, i) need one row, not two.  Native
+    (csrc_host/hostdraw.cpp) when built, numpy otherwise; both keep first-occurrence order, positives first."""
+    H = hostdraw()
+    if H is not None and hasattr(H, "merge_mirrored_pairs"):
+        pairs, w = H.merge_mirrored_pairs(pos.contiguous(), torch.from_numpy(np.ascontiguousarray(neg)), int(n), int(offset))
+        return pairs.numpy(), w.numpy()
+    out_p, out_w = [], []
+    for sign, e in ((1.0, pos.numpy()), (-1.0, neg)):
+        a, b = np.minimum(e[0], e[1]), np.maximum(e[0], e[1])
+        _, first, cnt = np.unique(a * n + b, return_index=True, return_counts=True)
+        order = np.argsort(first, kind="stable")
+        out_p.append(np.stack([a[first[order]], b[first[order]]]) + offset)
+        out_w.append((sign * cnt[order]).astype(np.float32))
+    return np.concatenate(out_p, axis=1), np.concatenate(out_w)
+
+
 def hostdraw():
     """The native module for the reference-order draws (csrc_host/hostdraw.cpp), or None when it has not been built: the
     Python implementations it mirrors then run instead (bit-identical, ~10x slower, and they hold the GIL)."""
@@ -207,6 +225,8 @@ class StepEngine:
         # from the shared torch generator (pretrain/tasks.py sample_negative_edges).  The engine keeps a stream of its own.
         self.neg_rng = neg_rng if neg_rng is not None else random.Random(0x9E3779B1 * (seed + 1))
         self._neg_native = None
+        # score each unordered pair once (the scorer is symmetric in (src, dst)); GMP_LP_MERGE=0 keeps the reference's ordered list
+        self.lp_merge = os.environ.get("GMP_LP_MERGE", "1") != "0"
         for t in tasks:
             if t not in SUPPORTED_TASKS:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
@@ -787,18 +807,26 @@ class StepEngine:
                     p.nfm_rows = rows
                     sizes[t] = rows[-1] * H
                 elif t == "link_pred":
-                    eds, npos = [], []
+                    eds, labs, npos, ordered = [], [], [], 0
                     for d, r0 in zip(D, r0s):
-                        pos = inp.host[d].edge_index.numpy() + r0
-                        eds += [pos, np.asarray(art[t][d], dtype=np.int64) + r0]
-                        npos.append((pos.shape[1], eds[-1].shape[1]))
+                        hb = inp.host[d]
+                        neg = np.asarray(art[t][d], dtype=np.int64)
+                        ordered += hb.edge_index.size(1) + neg.shape[1]
+                        if self.lp_merge:
+                            pairs, w = merge_mirrored_pairs(hb.edge_index, neg, hb.num_nodes, r0)
+                            eds.append(pairs); labs.append(w)
+                            npos.append((pairs.shape[1], 0))
+                        else:
+                            eds += [hb.edge_index.numpy() + r0, neg + r0]
+                            npos.append((eds[-2].shape[1], eds[-1].shape[1]))
+                            labs += [np.ones(npos[-1][0], dtype=np.float32), -np.ones(npos[-1][1], dtype=np.float32)]
                     e = np.concatenate(eds, axis=1)
-                    lab = np.concatenate([np.concatenate([np.ones(a, dtype=np.float32), np.zeros(b, dtype=np.float32)]) for a, b in npos])
+                    lab = np.concatenate(labs)
                     if e.shape[1] > self.KMAX:
                         raise L.GnnmpError("engine: too many link-prediction edges")
                     a64["lp_edges"] = e
                     p.lp_labels, p.lp_K = lab, e.shape[1]
-                    sizes[t] = e.shape[1]
+                    sizes[t] = ordered                    # the reference's count: BCE is a mean over its ordered list (tasks.py:120)
                     # block diagonal by domain: the decoder CSR is built one workgroup per (domain, orientation)
                     a32["lp_seg_ptr"] = np.asarray(r0s + [seg_ptr[-1]])
                     a32["lp_seg_eptr"] = np.concatenate([[0], np.cumsum([a + b for a, b in npos])])
@@ -1241,7 +1269,7 @@ class StepEngine:
             self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
             d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
             self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
-            self._chk(lib.gmp_sigmoid_bce_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
+            self._chk(lib.gmp_sigmoid_bce_signed_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
                                                       self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "sigmoid+bce")
             one = [0, K]
             self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],

@@ -301,6 +301,11 @@ int gmp_bce_sum_bwd(const float* p, const float* labels, const float* g_scale, f
  * loss = BCE(sigmoid(x), labels) summed, g_x = d (g_scale * loss) / d x; p_out (nullable) receives sigmoid(x). */
 int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, int64_t numel, const float* g_scale, float* loss,
                                 float* p_out, float* g_x, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+/* The same pass over pairs that carry a multiplicity: signed_weight[i] = +w for a positive pair, -w for a negative pair, w >= 1 the
+ * number of times the pair stands in the reference's list (the scorer of src/models/heads.py:57-67 is symmetric in (src, dst), so
+ * (i, j) and (j, i) need scoring once); loss term and g_x[i] are scaled by w.  With w = 1 everywhere: the call above, bit for bit. */
+int gmp_sigmoid_bce_signed_sum_fwd_bwd(const float* x, const float* signed_weight, int64_t numel, const float* g_scale, float* loss,
+                                       float* p_out, float* g_x, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t rows, int classes,
                               float* loss, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
 int gmp_cross_entropy_sum_bwd(const float* logits, const int64_t* target, int64_t rows, int classes,

@@ -1,4 +1,5 @@
 """Shared helpers for the module/step parity tests."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -83,12 +84,21 @@ def engine_gate_tapes(eng, plan, art):
                 if r1 > r0:
                     m.append((eng.hd["nfm_y1"][r0:r1] > 0).cpu())
             elif t == "link_pred":
-                k = eng_lp_count(eng, plan, art, d)
                 m += backbone(ss[0])
-                e = torch.from_numpy(plan.a64["lp_edges"][:, lp_off:lp_off + k]).long().to(eng.h[-1].device)
+                # the oracle scores the reference's ordered list (positives, then negatives); the engine holds one row per unordered
+                # pair (engine.merge_mirrored_pairs): look every ordered pair's row up by its (min, max) key
+                hb, r0 = eng.last_inputs.host[d], plan.seg_ptr[ss[0]]
+                ordered = np.concatenate([hb.edge_index.numpy(), np.asarray(art["link_pred"][d], dtype=np.int64)], axis=1) + r0
+                a, b = int(plan.a32["lp_seg_eptr"][di]), int(plan.a32["lp_seg_eptr"][di + 1])
+                rows, R = plan.a64["lp_edges"][:, a:b], plan.N + 1
+                key_rows = np.minimum(rows[0], rows[1]) * R + np.maximum(rows[0], rows[1])
+                order = np.argsort(key_rows, kind="stable")
+                key_ord = np.minimum(ordered[0], ordered[1]) * R + np.maximum(ordered[0], ordered[1])
+                at = order[np.searchsorted(key_rows[order], key_ord)] if b > a else np.zeros(0, dtype=np.int64)
+                assert (key_rows[at] == key_ord).all()
+                e = torch.from_numpy(ordered).long().to(eng.h[-1].device)
                 m.append(torch.sign(eng.h[-1][e[0]] - eng.h[-1][e[1]]).to(torch.int8).cpu())      # sign(hs - hd): the |.| feature's kink
-                m.append((eng.hd["lp_y1"][lp_off:lp_off + k] > 0).cpu())
-                lp_off += k
+                m.append((eng.hd["lp_y1"][a:b] > 0).cpu()[torch.from_numpy(at)])
             elif t == "node_contrast":
                 for si in ss:
                     m += backbone(si)
@@ -114,13 +124,6 @@ def engine_gate_tapes(eng, plan, art):
                 m.append((eng.hd["da_y1"][g0:g1] > 0).cpu())
         tapes[t] = GateTape(m)
     return tapes
-
-
-def eng_lp_count(eng, plan, art, d):
-    """edges scored for domain d by the link-prediction head: its positives + the drawn negatives"""
-    import numpy as np
-    pos = eng.last_inputs.host[d].edge_index.size(1)
-    return pos + np.asarray(art["link_pred"][d]).shape[1]
 
 
 def assert_grad_tight(got, want, gmax, what="", tol=2e-4):

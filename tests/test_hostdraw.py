@@ -110,3 +110,33 @@ def test_native_negative_sampler_replays_pythons_random(seed):
         assert torch.equal(got, want)
         assert tuple(nat.getstate().tolist()) == r_py.getstate()[1]
     assert drew                                           # at least one batch needed random draws
+
+
+def test_merged_pairs_hold_the_ordered_list_as_a_multiset(monkeypatch):
+    """engine.merge_mirrored_pairs: every ordered pair of the reference's list (positives, then negatives) stands in the merged list
+    as its (min, max) pair with the right sign, multiplicities add up to the ordered counts, and the native and numpy versions give
+    the same arrays (a directed edge, a duplicate and a self loop included)."""
+    import random
+    from gnn_pretraining_amd.engine import merge_mirrored_pairs
+    gen = torch.Generator().manual_seed(11)
+    cases = [(b.edge_index, sample_negative_edges(b, random.Random(2)).numpy(), b.num_nodes) for b in _batches() if b.num_graphs]
+    cases.append((torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 2, 3, 3]]), np.array([[0, 3, 0], [3, 0, 2]]), 4))
+    cases.append((torch.zeros(2, 0, dtype=torch.long), np.zeros((2, 0), dtype=np.int64), 0))
+    for pos, neg, n in cases:
+        pairs, w = merge_mirrored_pairs(pos, neg, n, 100)
+        with monkeypatch.context() as m:
+            m.setattr("gnn_pretraining_amd.engine._HOSTDRAW", None)
+            m.setattr("gnn_pretraining_amd.engine._HOSTDRAW_TRIED", True)
+            pairs_np, w_np = merge_mirrored_pairs(pos, neg, n, 100)
+        assert np.array_equal(pairs, pairs_np) and np.array_equal(w, w_np)
+        assert (pairs[0] <= pairs[1]).all() and pairs.dtype == np.int64 and w.dtype == np.float32
+        npos = int((w > 0).sum())
+        assert (w[:npos] > 0).all() and (w[npos:] < 0).all()                         # positives first
+        for sign, e, seg, ws in ((1, pos.numpy(), pairs[:, :npos], w[:npos]), (-1, neg, pairs[:, npos:], w[npos:])):
+            keys = [(int(min(a, b)) + 100, int(max(a, b)) + 100) for a, b in e.T]
+            want = {}
+            for k in keys:
+                want[k] = want.get(k, 0) + 1
+            got = {(int(a), int(b)): int(sign * x) for a, b, x in zip(seg[0], seg[1], ws)}
+            assert got == want and len(got) == seg.shape[1]
+            assert list(got) == list(dict.fromkeys(keys))                              # first-occurrence order
