@@ -407,14 +407,14 @@ def main() -> None:
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
-    busy0, wait0 = pf.busy_s, pf.wait_s
+    busy0, wait0, draw0 = pf.busy_s, pf.wait_s, pf.draw_s
     t0 = time.perf_counter()
     advance(engine, temperature, gen, it, a.steps)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    pf.busy_s, pf.wait_s = pf.busy_s - busy0, pf.wait_s - wait0
+    pf.busy_s, pf.wait_s, pf.draw_s = pf.busy_s - busy0, pf.wait_s - wait0, pf.draw_s - draw0
     for _ in it:                                    # (the prefetcher's end marker)
         pass
     if world > 1:
@@ -425,7 +425,7 @@ def main() -> None:
     hm = engine.host_ms
     log(f"{a.steps} steps in {elapsed:.3f} s; last-step losses {engine.losses()}")
     log("host ms/step: " + ", ".join(f"{k} {hm[k] / max(hm['steps'], 1):.2f}" for k in ("draw", "plan", "upload", "launch")) +
-        f"; prefetch thread busy {pf.busy_s / max(a.steps, 1) * 1e3:.2f}, launcher waited for it {pf.wait_s / max(a.steps, 1) * 1e3:.2f}")
+        f"; prefetch threads busy: draws {pf.draw_s / max(a.steps, 1) * 1e3:.2f}, layout {pf.busy_s / max(a.steps, 1) * 1e3:.2f}, launcher waited for them {pf.wait_s / max(a.steps, 1) * 1e3:.2f}")
     roof = roof_gemm = cpu = None
     if rank == 0 and not a.no_roofline:
         roof = aggregation_roofline(device)

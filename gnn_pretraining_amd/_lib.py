@@ -77,6 +77,9 @@ _SIGS: Dict[str, tuple] = {
     "gmp_bn_workspace_bytes": (sz, [i64, i32, i32, i64]),
     "gmp_bn_fwd": (C.c_int, [p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, C.POINTER(BnConfig), p, sz, p]),
     "gmp_bn_param_grads": (C.c_int, [p, i32, i32, p, p, p, p, p, i32, p]),
+    "gmp_linear_bn_supported": (C.c_int, [i32, i64, i32, i32]),
+    "gmp_linear_bn_fwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, i32, p, p, p, p, p, p, C.POINTER(BnConfig), p]),
+    "gmp_linear_bn_bwd_input": (C.c_int, [p, p, p, p, i32, i64, i64, i32, i32, p, p, p, p, p, p, sz, C.POINTER(BnConfig), p]),
     "gmp_bn_running_update_batch": (C.c_int, [i32, p, i32, p, p, p, p, p, p, p, p]),
     "gmp_bn_running_update": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p]),
     "gmp_bn_bwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, p, p, p, p, p, i32,

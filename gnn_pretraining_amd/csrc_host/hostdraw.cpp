@@ -197,14 +197,24 @@ struct PyRandom {
                 const double prob = 1.0 - (double)nidx / (double)pop;
                 const int64_t size = (int64_t)(1.1 * (double)num_neg / prob);
                 neg.clear();
+                if (pop <= size) {
+                    // every try is arange(pop) and draws nothing: the first one takes every non-edge slot in order, the other two find
+                    // them all taken -- so the result is the first num_neg non-edges, emitted row by row without the slot division
+                    int64_t left = num_neg;
+                    for (int64_t r = 0; r < n && left > 0; ++r) {
+                        const char* row = is_edge.data() + (size_t)(r * (n - 1));
+                        for (int64_t j = 0; j < n - 1 && left > 0; ++j)
+                            if (!row[j]) {
+                                os.push_back(r + s);
+                                od.push_back(j + (r <= j ? 1 : 0) + s);
+                                --left;
+                            }
+                    }
+                    continue;
+                }
                 taken.assign((size_t)pop, 0);
                 for (int attempt = 0; attempt < 3; ++attempt) {
-                    if (pop <= size) {
-                        rnd.resize((size_t)pop);
-                        for (int64_t i = 0; i < pop; ++i) rnd[(size_t)i] = i;
-                    } else {
-                        sample_range(pop, size, rnd, pool, seen);
-                    }
+                    sample_range(pop, size, rnd, pool, seen);
                     for (int64_t v : rnd)
                         if (!is_edge[(size_t)v] && !taken[(size_t)v]) neg.push_back(v);
                     for (int64_t v : neg) taken[(size_t)v] = 1;      // np.isin(rnd, neg_idx) of the NEXT try (duplicates within one
@@ -318,46 +328,63 @@ std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor e
 
 // The link-prediction scorer's features [hs+hd, hs*hd, |hs-hd|] (src/models/heads.py:57-61) are symmetric in (src, dst), so the
 // ordered pairs (i, j) and (j, i) of one label score identically: the engine scores each unordered pair once and carries its
-// multiplicity as a weight.  pos / neg: [2, E] local node ids of ONE domain batch (n nodes); returns pairs [2, K'] (min, max) +
-// offset, in first-occurrence order (positives first), and signed multiplicities (+count for positives, -count for negatives).
-std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, int64_t n, int64_t offset) {
+// multiplicity as a weight.  pos / neg: [2, E] local node ids of ONE domain batch, each grouped by graph in batch order (PyG's
+// collation and batched_negative_sampling both are); ptr: the batch's node offsets.  Returns pairs [2, K'] (min, max) + offset --
+// all positives, then all negatives, each in first-occurrence order -- and signed multiplicities (+count positives, -count
+// negatives).  Pairs never cross graphs, so the counting table is one graph's n x n (a few KB: it stays in L1).
+std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at::Tensor ptr, int64_t offset) {
     for (const at::Tensor* t : {&pos, &neg})
         TORCH_CHECK(t->dim() == 2 && t->size(0) == 2 && t->scalar_type() == at::kLong && t->is_contiguous() && t->device().is_cpu(),
                     "hostdraw: pairs must be contiguous CPU int64 [2, E]");
-    TORCH_CHECK(n >= 0, "hostdraw: negative node count");
-    std::vector<int64_t> a_out, b_out;
-    std::vector<float> w_out;
+    TORCH_CHECK(ptr.dim() == 1 && ptr.numel() >= 1 && ptr.scalar_type() == at::kLong && ptr.is_contiguous(), "hostdraw: ptr");
+    const int64_t cap = pos.size(1) + neg.size(1);
+    at::Tensor pairs = at::empty({2, cap}, at::kLong), w = at::empty({cap}, at::kFloat);
+    int64_t out = 0;
+    const char* err = nullptr;
     {
         pybind11::gil_scoped_release nogil;
-        const bool dense = n <= 4096;
-        std::vector<uint16_t> count(dense ? (size_t)(n * n) : 0, 0);
-        std::unordered_map<int64_t, int32_t> sparse;
-        a_out.reserve((size_t)(pos.size(1) + neg.size(1)) / 2 + 16);
-        b_out.reserve(a_out.capacity()); w_out.reserve(a_out.capacity());
-        for (int g = 0; g < 2; ++g) {
-            const at::Tensor& t = g ? neg : pos;
+        int64_t *oa = pairs.data_ptr<int64_t>(), *ob = oa + cap;
+        float* ow = w.data_ptr<float>();
+        const int64_t* p = ptr.data_ptr<int64_t>();
+        const int64_t G = ptr.numel() - 1;
+        std::vector<uint16_t> count;
+        for (int grp = 0; grp < 2 && !err; ++grp) {
+            const at::Tensor& t = grp ? neg : pos;
             const int64_t E = t.size(1);
             const int64_t *s = t.data_ptr<int64_t>(), *d = s + E;
-            const float sign = g ? -1.f : 1.f;
-            for (int64_t e = 0; e < E; ++e) {
-                const int64_t a = std::min(s[e], d[e]), b = std::max(s[e], d[e]);
-                TORCH_CHECK(a >= 0 && b < n, "hostdraw: pair endpoint outside the domain batch");
-                if (dense) { TORCH_CHECK(count[(size_t)(a * n + b)] < 65535, "hostdraw: pair multiplicity overflow"); ++count[(size_t)(a * n + b)]; }
-                else ++sparse[a * n + b];
+            const float sign = grp ? -1.f : 1.f;
+            int64_t e = 0;
+            for (int64_t gi = 0; gi < G && e < E && !err; ++gi) {
+                const int64_t lo = p[gi], hi = p[gi + 1], n = hi - lo;
+                int64_t e1 = e;
+                while (e1 < E && s[e1] >= lo && s[e1] < hi) ++e1;             // this graph's run of pairs
+                if (e1 == e) continue;
+                if (n > 4096) { err = "hostdraw: graph too large for the pair table"; break; }
+                if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);
+                for (int64_t k = e; k < e1; ++k) {
+                    const int64_t x = s[k] - lo, y = d[k] - lo;
+                    if (y < 0 || y >= n) { err = "hostdraw: pair crosses graphs"; break; }
+                    uint16_t& c = count[(size_t)((x < y ? x : y) * n + (x < y ? y : x))];
+                    if (c == 65535) { err = "hostdraw: pair multiplicity overflow"; break; }
+                    ++c;
+                }
+                if (err) break;
+                for (int64_t k = e; k < e1; ++k) {
+                    const int64_t x = s[k] - lo, y = d[k] - lo, a = x < y ? x : y, b = x < y ? y : x;
+                    uint16_t& c = count[(size_t)(a * n + b)];
+                    if (c) {
+                        oa[out] = a + lo + offset; ob[out] = b + lo + offset; ow[out] = sign * (float)c;
+                        ++out;
+                        c = 0;
+                    }
+                }
+                e = e1;
             }
-            for (int64_t e = 0; e < E; ++e) {
-                const int64_t a = std::min(s[e], d[e]), b = std::max(s[e], d[e]);
-                int64_t c;
-                if (dense) { c = count[(size_t)(a * n + b)]; count[(size_t)(a * n + b)] = 0; }
-                else { auto it = sparse.find(a * n + b); c = it->second; it->second = 0; }
-                if (c) { a_out.push_back(a + offset); b_out.push_back(b + offset); w_out.push_back(sign * (float)c); }
-            }
-            sparse.clear();
+            if (!err && e != E) err = "hostdraw: pairs are not grouped by graph in batch order";
         }
     }
-    at::Tensor w = at::empty({(int64_t)w_out.size()}, at::kFloat);
-    if (!w_out.empty()) std::memcpy(w.data_ptr<float>(), w_out.data(), w_out.size() * sizeof(float));
-    return {to_tensor2(a_out, b_out), w};
+    TORCH_CHECK(!err, err);
+    return {pairs.narrow(1, 0, out).contiguous(), w.narrow(0, 0, out).contiguous()};
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {

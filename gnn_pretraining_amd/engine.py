@@ -160,20 +160,21 @@ def L_view_sizes(ptr_host):
 _HOSTDRAW, _HOSTDRAW_TRIED = None, False
 
 
-def merge_mirrored_pairs(pos: torch.Tensor, neg: np.ndarray, n: int, offset: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Unordered pairs [2, K'] (+offset) and signed multiplicities (+w positive, -w negative) of one domain's scored pairs: the
-    LP scorer's features (heads.py:57-61) are symmetric in (src, dst), so (i, j) and (j, i) need one row, not two.  Native
-    (csrc_host/hostdraw.cpp) when built, numpy otherwise; both keep first-occurrence order, positives first."""
+def merge_mirrored_pairs(b: Batch, neg: np.ndarray, offset: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Unordered pairs [2, K'] (+offset) and signed multiplicities (+w positive, -w negative) of one domain batch's scored pairs (its
+    edges, then the drawn negatives): the LP scorer's features (heads.py:57-61) are symmetric in (src, dst), so (i, j) and (j, i) need
+    one row, not two.  Native (csrc_host/hostdraw.cpp) when built, numpy otherwise; both keep first-occurrence order, positives first."""
     H = hostdraw()
     if H is not None and hasattr(H, "merge_mirrored_pairs"):
-        pairs, w = H.merge_mirrored_pairs(pos.contiguous(), torch.from_numpy(np.ascontiguousarray(neg)), int(n), int(offset))
+        ptr, _, ei = _host_tensors(b)
+        pairs, w = H.merge_mirrored_pairs(ei, torch.from_numpy(np.ascontiguousarray(neg)), ptr, int(offset))
         return pairs.numpy(), w.numpy()
-    out_p, out_w = [], []
-    for sign, e in ((1.0, pos.numpy()), (-1.0, neg)):
-        a, b = np.minimum(e[0], e[1]), np.maximum(e[0], e[1])
-        _, first, cnt = np.unique(a * n + b, return_index=True, return_counts=True)
+    out_p, out_w, n = [], [], max(b.num_nodes, 1)
+    for sign, e in ((1.0, b.edge_index.numpy()), (-1.0, neg)):
+        lo, hi = np.minimum(e[0], e[1]), np.maximum(e[0], e[1])
+        _, first, cnt = np.unique(lo * n + hi, return_index=True, return_counts=True)
         order = np.argsort(first, kind="stable")
-        out_p.append(np.stack([a[first[order]], b[first[order]]]) + offset)
+        out_p.append(np.stack([lo[first[order]], hi[first[order]]]) + offset)
         out_w.append((sign * cnt[order]).astype(np.float32))
     return np.concatenate(out_p, axis=1), np.concatenate(out_w)
 
@@ -813,7 +814,7 @@ class StepEngine:
                         neg = np.asarray(art[t][d], dtype=np.int64)
                         ordered += hb.edge_index.size(1) + neg.shape[1]
                         if self.lp_merge:
-                            pairs, w = merge_mirrored_pairs(hb.edge_index, neg, hb.num_nodes, r0)
+                            pairs, w = merge_mirrored_pairs(hb, neg, r0)
                             eds.append(pairs); labs.append(w)
                             npos.append((pairs.shape[1], 0))
                         else:
@@ -1824,7 +1825,8 @@ class StepPrefetcher:
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._err = None
 
-        self.busy_s, self.wait_s, self.items = 0.0, 0.0, 0       # producer time in prepare(), consumer time blocked in get()
+        # producer time in prepare() (host-order draws: in plan(), with draw() on its own thread in draw_s), consumer time blocked in get()
+        self.busy_s, self.draw_s, self.wait_s, self.items = 0.0, 0.0, 0.0, 0
 
         def work() -> None:
             import time as _t
@@ -1854,15 +1856,38 @@ class StepPrefetcher:
                     return
                 for inp in inputs:
                     t0 = _t.perf_counter()
-                    item = (inp, engine.prepare(inp, gen))
-                    self.busy_s += _t.perf_counter() - t0
-                    self.q.put(item)
+                    art = engine.draw(inp, gen)
+                    self.draw_s += _t.perf_counter() - t0
+                    planq.put((inp, art))
             except BaseException as e:           # surfaced on the consumer side
+                self._err = e
+            (self.q if engine.rng_mode == "device" else planq).put(None)
+
+        # Host-order draws: a second stage lays the segments out (engine.plan: numpy, no RNG, no engine state), so the draws of step
+        # t + 1 (native code, GIL released) run beside the layout of step t -- together they were 1.3 of a 1.57 ms step.
+        planq: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def layout() -> None:
+            import time as _t
+            try:
+                while True:
+                    item = planq.get()
+                    if item is None:
+                        break
+                    inp, art = item
+                    t0 = _t.perf_counter()
+                    out = (inp, (art, engine.plan(inp, art)))
+                    self.busy_s += _t.perf_counter() - t0
+                    self.q.put(out)
+            except BaseException as e:
                 self._err = e
             self.q.put(None)
 
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
+        if engine.rng_mode != "device":
+            self.plan_thread = threading.Thread(target=layout, daemon=True)
+            self.plan_thread.start()
 
     def __iter__(self):
         import time as _t

@@ -118,16 +118,17 @@ def test_merged_pairs_hold_the_ordered_list_as_a_multiset(monkeypatch):
     the same arrays (a directed edge, a duplicate and a self loop included)."""
     import random
     from gnn_pretraining_amd.engine import merge_mirrored_pairs
-    gen = torch.Generator().manual_seed(11)
-    cases = [(b.edge_index, sample_negative_edges(b, random.Random(2)).numpy(), b.num_nodes) for b in _batches() if b.num_graphs]
-    cases.append((torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 2, 3, 3]]), np.array([[0, 3, 0], [3, 0, 2]]), 4))
-    cases.append((torch.zeros(2, 0, dtype=torch.long), np.zeros((2, 0), dtype=np.int64), 0))
-    for pos, neg, n in cases:
-        pairs, w = merge_mirrored_pairs(pos, neg, n, 100)
+    cases = [(b, sample_negative_edges(b, random.Random(2)).numpy()) for b in _batches() if b.num_graphs]
+    odd = Batch.from_data_list([Data(torch.zeros(4, 4), torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 2, 3, 3]]), torch.zeros(1, dtype=torch.long), torch.zeros(12)),
+                                Data(torch.zeros(3, 4), torch.tensor([[0, 0], [1, 1]]), torch.zeros(1, dtype=torch.long), torch.zeros(12))])
+    cases.append((odd, np.array([[0, 3, 0, 4, 6], [3, 0, 2, 6, 4]])))              # a directed edge, a self loop, a duplicate edge
+    for b, neg in cases:
+        pos = b.edge_index
+        pairs, w = merge_mirrored_pairs(b, neg, 100)
         with monkeypatch.context() as m:
             m.setattr("gnn_pretraining_amd.engine._HOSTDRAW", None)
             m.setattr("gnn_pretraining_amd.engine._HOSTDRAW_TRIED", True)
-            pairs_np, w_np = merge_mirrored_pairs(pos, neg, n, 100)
+            pairs_np, w_np = merge_mirrored_pairs(b, neg, 100)
         assert np.array_equal(pairs, pairs_np) and np.array_equal(w, w_np)
         assert (pairs[0] <= pairs[1]).all() and pairs.dtype == np.int64 and w.dtype == np.float32
         npos = int((w > 0).sum())
