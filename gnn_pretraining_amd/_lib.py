@@ -61,6 +61,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_csr_build": (C.c_int, [p, i64, i64, p, p, p, p, p, p, p, p, sz, p]),
     "gmp_csr_build_segmented": (C.c_int, [p, i64, i64, p, p, i32, i64, i64, p, p, p, p, p, p, p, p]),
     "gmp_gin_aggregate_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p]),
+    "gmp_gin_aggregate_fwd_rows": (C.c_int, [p, p, p, p, p, i64, i64, i32, p]),
     "gmp_gin_aggregate_bwd_workspace_bytes": (sz, [i64, i32]),
     "gmp_gin_aggregate_bwd": (C.c_int, [p, p, p, p, p, p, p, i64, i32, p, sz, p]),
     "gmp_segment_sum": (C.c_int, [p, p, p, p, i64, i32, i32, i32, p]),

@@ -494,6 +494,20 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
                                                       nullptr, out, nullptr, N, F4);
 }
 
+// Rows [row0, row1) of the same aggregation (cache-resident sizes): the stacked step runs its forward in two halves on two streams.
+// x and col keep the whole batch's numbering; only the output rows are restricted.
+extern "C" int gmp_gin_aggregate_fwd_rows(const float* x, const int32_t* rowptr, const int32_t* col, const float* eps, float* out,
+                                          int64_t row0, int64_t row1, int feat, gmp_stream_t stream) {
+    if (int rc = check_feat("gin_aggregate_fwd_rows", feat)) return rc;
+    if (row0 < 0 || row1 < row0) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd_rows: bad row range");
+    if (row1 == row0) return GMP_OK;
+    if (!x || !rowptr || !out) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd_rows: null pointer");
+    const int F4 = feat / 4;
+    Plan p = make_plan(row1 - row0);
+    return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, (hipStream_t)stream, x, rowptr + row0, col, x + row0 * feat, eps, nullptr,
+                                                      out + row0 * feat, nullptr, row1 - row0, F4);
+}
+
 extern "C" size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t N, int feat) {
     (void)feat;
     return (size_t)(N > 0 ? N : 1) * sizeof(float) + 256 + 1024 * sizeof(float);   // one <g, x> per row (+ block partials), summed in a second pass

@@ -16,10 +16,12 @@ namespace {
     } while (0)
 
 constexpr int H = 256;
-constexpr int NEV = 4 + 2 * GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 7;
+constexpr int NEV = 4 + 2 * GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 9;
 constexpr int EV_LAYER0_DONE = NEV - 4, EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;
 constexpr int EV_HEAD_PARAMS = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS;   // [task], [MAX_TASKS] = the heads of the main stream: weight-gradient GEMMs done
 constexpr int EV_MAIN_HEADS = EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS + 1;           // main: input halves of its own heads done
+constexpr int EV_FWD_FORK = EV_MAIN_HEADS + 1, EV_FWD_JOIN = EV_MAIN_HEADS + 2;  // split forward: main -> second stream, and back
+static_assert(EV_FWD_JOIN < NEV - 4, "event pool too small");
 // ev[NEV - 1]: running statistics done (aux)
 
 // Gate flags (d.sync_flags, int32[64], all compared against the step's epoch): the same dependencies as the events above, carried
@@ -38,6 +40,8 @@ enum {
     F_BWD_DONE = 36,                   // main -> exchange stream: backward done
     F_AUX_DONE = 37,                   // aux -> main: everything aux did for this step is done
     F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
+    F_FWD_FORK = 39,                   // main -> the second forward stream: encoders done (split forward)
+    F_FWD_JOIN = 40,                   // second forward stream -> main: its half of the stacked forward is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
@@ -385,19 +389,47 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     (void)hipStreamWaitEvent(main, ev[1], 0);
     if (timing) (void)hipEventRecord(phase_events()[1], main);
 
-    // ---- stacked backbone forward
+    // ---- stacked backbone forward: one pass on main, or two row ranges on two streams (gnnmp_step.h fwd_split_*)
+    hipStream_t fwd_b = main;
+    for (int ti = 0; ti < T; ++ti) {
+        hipStream_t ts = (hipStream_t)task_streams[ti];
+        if (ts != main && ts != aux) { fwd_b = ts; break; }
+    }
+    const size_t bn_fwd_slice = gmp_bn_workspace_bytes(N, 2 * H, d.S, d.max_seg);
+    const bool split_fwd = d.fwd_split_seg > 0 && d.fwd_split_seg < d.S && d.fwd_split_row > 0 && d.fwd_split_row < N && fwd_b != main &&
+                           d.bn_ws_bytes >= 2 * bn_fwd_slice && N < 65536;
+    struct Range { int s0, s1; int64_t r0, r1; hipStream_t st; void* ws; };
+    Range ranges[2] = {{0, split_fwd ? d.fwd_split_seg : d.S, 0, split_fwd ? d.fwd_split_row : N, main, d.bn_ws},
+                       {d.fwd_split_seg, d.S, d.fwd_split_row, N, fwd_b, (char*)d.bn_ws + bn_fwd_slice}};
+    if (split_fwd) {
+        GMP_TRY(signal(F_FWD_FORK, ev[EV_FWD_FORK], main));
+        GMP_TRY(await(F_FWD_FORK, ev[EV_FWD_FORK], fwd_b));
+    }
     for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
         const gmp_layer_desc& L = d.layer[l];
-        GMP_TRY(gmp_gin_aggregate_fwd(d.h[l], d.csr[0], d.csr[1], d.flat + L.off_eps, L.a, N, H, main_));
-        GMP_TRY(gemm(GMP_GEMM_NT, L.a, d.flat + L.off_w1, d.flat + L.off_b1, L.z1, N, 2 * H, H, H, H, 2 * H, false, main_));
-        c = bn_cfg(d, true, false, 0);
-        GMP_TRY(gmp_bn_fwd(L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, defer ? nullptr : L.rm1,
-                           defer ? nullptr : L.rv1, L.m1, L.s1, L.r1, &c, d.bn_ws, d.bn_ws_bytes, main_));
-        GMP_TRY(gemm(GMP_GEMM_NT, L.r1, d.flat + L.off_w2, d.flat + L.off_b2, L.z2, N, H, 2 * H, 2 * H, 2 * H, H, false, main_));
-        c = bn_cfg(d, true, true, 10 + l);
-        GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, defer ? nullptr : L.rm2,
-                           defer ? nullptr : L.rv2, L.m2, L.s2, d.h[l + 1], &c, d.bn_ws, d.bn_ws_bytes, main_));
+        for (int k = 0; k < (split_fwd ? 2 : 1); ++k) {
+            const Range& R = ranges[k];
+            gmp_stream_t st = (gmp_stream_t)R.st;
+            const int64_t M = R.r1 - R.r0;
+            const int Sk = R.s1 - R.s0;
+            const int32_t* sp = d.seg_ptr + R.s0;
+            if (split_fwd) GMP_TRY(gmp_gin_aggregate_fwd_rows(d.h[l], d.csr[0], d.csr[1], d.flat + L.off_eps, L.a, R.r0, R.r1, H, st));
+            else GMP_TRY(gmp_gin_aggregate_fwd(d.h[l], d.csr[0], d.csr[1], d.flat + L.off_eps, L.a, N, H, st));
+            GMP_TRY(gemm(GMP_GEMM_NT, L.a + R.r0 * H, d.flat + L.off_w1, d.flat + L.off_b1, L.z1 + R.r0 * 2 * H, M, 2 * H, H, H, H, 2 * H, false, st));
+            c = bn_cfg(d, true, false, 0);
+            // (absolute row numbers in seg_ptr: the BatchNorm takes whole-batch base pointers and this range's segments)
+            GMP_TRY(gmp_bn_fwd(L.z1, nullptr, sp, nullptr, Sk, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, defer ? nullptr : L.rm1,
+                               defer ? nullptr : L.rv1, L.m1 + (size_t)R.s0 * 2 * H, L.s1 + (size_t)R.s0 * 2 * H, L.r1, &c, R.ws, split_fwd ? bn_fwd_slice : d.bn_ws_bytes, st));
+            GMP_TRY(gemm(GMP_GEMM_NT, L.r1 + R.r0 * 2 * H, d.flat + L.off_w2, d.flat + L.off_b2, L.z2 + R.r0 * H, M, H, 2 * H, 2 * H, 2 * H, H, false, st));
+            c = bn_cfg(d, true, true, 10 + l);
+            GMP_TRY(gmp_bn_fwd(L.z2, d.h[l], sp, nullptr, Sk, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, defer ? nullptr : L.rm2,
+                               defer ? nullptr : L.rv2, L.m2 + (size_t)R.s0 * H, L.s2 + (size_t)R.s0 * H, d.h[l + 1], &c, R.ws, split_fwd ? bn_fwd_slice : d.bn_ws_bytes, st));
+        }
         if (timing && l + 1 < GMP_STEP_LAYERS) (void)hipEventRecord(phase_events()[2 + l], main);
+    }
+    if (split_fwd) {
+        GMP_TRY(signal(F_FWD_JOIN, ev[EV_FWD_JOIN], fwd_b));
+        GMP_TRY(await(F_FWD_JOIN, ev[EV_FWD_JOIN], main));
     }
 
     // ---- task heads, each on its own stream

@@ -63,26 +63,29 @@ void check_ptrs(const at::Tensor& ptr, const at::Tensor& eptr, const at::Tensor&
 
 }  // namespace
 
-// models/pretrain_model.py draw_mask_indices
-at::Tensor mask_indices(at::Tensor ptr, at::Generator gen) {
-    TORCH_CHECK(ptr.dtype() == at::kLong && ptr.is_contiguous() && ptr.device().is_cpu(), "hostdraw: ptr");
-    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
-    std::vector<int64_t> out, perm;
-    {
-        pybind11::gil_scoped_release nogil;
-        std::lock_guard<std::mutex> lock(impl->mutex_);
-        Rng rng{impl};
-        const int64_t* p = ptr.data_ptr<int64_t>();
-        for (int64_t gidx = 0; gidx + 1 < ptr.numel(); ++gidx) {
-            const int64_t s = p[gidx], n = p[gidx + 1] - s;
-            if (n >= 3) {
-                const int64_t k = std::max<int64_t>(1, (int64_t)(n * 0.15));
-                rng.randperm(n, perm);
-                for (int64_t i = 0; i < k; ++i) out.push_back(perm[(size_t)i] + s);
-            }
+// models/pretrain_model.py draw_mask_indices.  The *_core functions neither touch the GIL nor lock the generator: their callers do
+// (once per call for the single-artefact entry points, once per STEP for draw_step below).
+at::Tensor mask_indices_core(const at::Tensor& ptr, at::CPUGeneratorImpl* impl) {
+    static thread_local std::vector<int64_t> out, perm;
+    out.clear();
+    Rng rng{impl};
+    const int64_t* p = ptr.data_ptr<int64_t>();
+    for (int64_t gidx = 0; gidx + 1 < ptr.numel(); ++gidx) {
+        const int64_t s = p[gidx], n = p[gidx + 1] - s;
+        if (n >= 3) {
+            const int64_t k = std::max<int64_t>(1, (int64_t)(n * 0.15));
+            rng.randperm(n, perm);
+            for (int64_t i = 0; i < k; ++i) out.push_back(perm[(size_t)i] + s);
         }
     }
     return to_tensor(out);
+}
+at::Tensor mask_indices(at::Tensor ptr, at::Generator gen) {
+    TORCH_CHECK(ptr.dtype() == at::kLong && ptr.is_contiguous() && ptr.device().is_cpu(), "hostdraw: ptr");
+    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+    pybind11::gil_scoped_release nogil;
+    std::lock_guard<std::mutex> lock(impl->mutex_);
+    return mask_indices_core(ptr, impl);
 }
 
 // ---- pretrain/tasks.py sample_negative_edges: PyG's batched_negative_sampling, drawn from PYTHON's random ---------------------
@@ -169,10 +172,15 @@ struct PyRandom {
     // sample_negative_edges(batch, rng) for a whole domain batch
     at::Tensor negative_edges(at::Tensor ptr, at::Tensor eptr, at::Tensor edge_index) {
         check_ptrs(ptr, eptr, edge_index);
-        std::vector<int64_t> os, od, rnd, pool, neg;
-        std::vector<char> is_edge, taken, seen;
+        pybind11::gil_scoped_release nogil;
+        return negative_edges_core(ptr, eptr, edge_index);
+    }
+    at::Tensor negative_edges_core(const at::Tensor& ptr, const at::Tensor& eptr, const at::Tensor& edge_index) {
+        // scratch that keeps its capacity across calls (a fresh 100 KB vector per call grows through malloc's mmap threshold: page faults)
+        static thread_local std::vector<int64_t> os, od, rnd, pool, neg;
+        static thread_local std::vector<char> is_edge, taken, seen;
+        os.clear(); od.clear();
         {
-            pybind11::gil_scoped_release nogil;
             const int64_t *p = ptr.data_ptr<int64_t>(), *ep = eptr.data_ptr<int64_t>(), *src = edge_index.data_ptr<int64_t>();
             const int64_t E = edge_index.size(1), num_neg = E;
             const int64_t* dst = src + E;
@@ -239,17 +247,13 @@ struct PyRandom {
 // engine.StepEngine._draw_views over pretrain/augmentations.py _augment_one: two views of every graph of a domain batch.
 // Returns, per view: rows (kept nodes, batch numbering), edges [2, e'] (view numbering), ptr [B+1], rowmask (bit c set = column c
 // zeroed; empty tensor when no graph of the view drew an attribute mask), common (view-local ids kept in BOTH views).
-std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor edge_index, int64_t num_features, at::Generator gen) {
-    check_ptrs(ptr, eptr, edge_index);
-    TORCH_CHECK(num_features >= 0 && num_features <= 64, "hostdraw: attribute masks are 64-bit column sets");
-    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+std::vector<at::Tensor> draw_views_core(const at::Tensor& ptr, const at::Tensor& eptr, const at::Tensor& edge_index, int64_t num_features,
+                                        at::CPUGeneratorImpl* impl) {
     struct Acc {
         std::vector<int64_t> rows, es, ed, ptr{0}, masks, common;
         bool any_mask = false;
     } acc[2];
     {
-        pybind11::gil_scoped_release nogil;
-        std::lock_guard<std::mutex> lock(impl->mutex_);
         Rng rng{impl};
         const int64_t *p = ptr.data_ptr<int64_t>(), *ep = eptr.data_ptr<int64_t>(), *src = edge_index.data_ptr<int64_t>();
         const int64_t E = edge_index.size(1);
@@ -326,6 +330,65 @@ std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor e
     return out;
 }
 
+std::vector<at::Tensor> draw_views(at::Tensor ptr, at::Tensor eptr, at::Tensor edge_index, int64_t num_features, at::Generator gen) {
+    check_ptrs(ptr, eptr, edge_index);
+    TORCH_CHECK(num_features >= 0 && num_features <= 64, "hostdraw: attribute masks are 64-bit column sets");
+    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+    pybind11::gil_scoped_release nogil;
+    std::lock_guard<std::mutex> lock(impl->mutex_);
+    return draw_views_core(ptr, eptr, edge_index, num_features, impl);
+}
+
+// engine.StepEngine.draw (rng_mode 'reference') in ONE call: every artefact of a step, tasks in the given order, domains in the given
+// order -- the order the reference consumes its generator in (pretrain.py:113-155 over tasks.py compute_loss) -- with the GIL
+// released and the generator locked once.  kinds: 0 masks, 1 negatives, 2 node-contrast views, 3 graph-contrast views (None for a
+// domain with fewer than two graphs, tasks.py:241).  Result [task][domain]: () for a domain without graphs, (tensor,) for masks /
+// negatives, the ten tensors of draw_views for views, None where the reference skips the pair.
+pybind11::list draw_step(std::vector<int> kinds, std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, int64_t>> doms, at::Generator gen,
+                         PyRandom& negatives) {
+    for (auto& dm : doms) {
+        check_ptrs(std::get<0>(dm), std::get<1>(dm), std::get<2>(dm));
+        TORCH_CHECK(std::get<3>(dm) >= 0 && std::get<3>(dm) <= 64, "hostdraw: attribute masks are 64-bit column sets");
+    }
+    for (int k : kinds) TORCH_CHECK(k >= 0 && k <= 3, "hostdraw: unknown artefact kind");
+    auto* impl = at::check_generator<at::CPUGeneratorImpl>(gen);
+    const size_t T = kinds.size(), D = doms.size();
+    std::vector<std::vector<at::Tensor>> res(T * D);
+    std::vector<char> none(T * D, 0);
+    {
+        pybind11::gil_scoped_release nogil;
+        std::lock_guard<std::mutex> lock(impl->mutex_);
+        for (size_t t = 0; t < T; ++t)
+            for (size_t di = 0; di < D; ++di) {
+                const at::Tensor &ptr = std::get<0>(doms[di]), &eptr = std::get<1>(doms[di]), &ei = std::get<2>(doms[di]);
+                const int64_t B = ptr.numel() - 1;
+                auto& r = res[t * D + di];
+                if (B <= 0) continue;
+                switch (kinds[t]) {
+                    case 0: r.push_back(mask_indices_core(ptr, impl)); break;
+                    case 1: r.push_back(negatives.negative_edges_core(ptr, eptr, ei)); break;
+                    case 2: r = draw_views_core(ptr, eptr, ei, std::get<3>(doms[di]), impl); break;
+                    default:
+                        if (B >= 2) r = draw_views_core(ptr, eptr, ei, std::get<3>(doms[di]), impl);
+                        else none[t * D + di] = 1;
+                }
+            }
+    }
+    pybind11::list out;
+    for (size_t t = 0; t < T; ++t) {
+        pybind11::list row;
+        for (size_t di = 0; di < D; ++di) {
+            if (none[t * D + di]) { row.append(pybind11::none()); continue; }
+            pybind11::tuple tup(res[t * D + di].size());
+            for (size_t i = 0; i < res[t * D + di].size(); ++i) tup[i] = pybind11::cast(res[t * D + di][i]);
+            row.append(tup);
+        }
+        out.append(row);
+    }
+    return out;
+}
+
+
 // The link-prediction scorer's features [hs+hd, hs*hd, |hs-hd|] (src/models/heads.py:57-61) are symmetric in (src, dst), so the
 // ordered pairs (i, j) and (j, i) of one label score identically: the engine scores each unordered pair once and carries its
 // multiplicity as a weight.  pos / neg: [2, E] local node ids of ONE domain batch, each grouped by graph in batch order (PyG's
@@ -338,16 +401,18 @@ std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at:
                     "hostdraw: pairs must be contiguous CPU int64 [2, E]");
     TORCH_CHECK(ptr.dim() == 1 && ptr.numel() >= 1 && ptr.scalar_type() == at::kLong && ptr.is_contiguous(), "hostdraw: ptr");
     const int64_t cap = pos.size(1) + neg.size(1);
-    at::Tensor pairs = at::empty({2, cap}, at::kLong), w = at::empty({cap}, at::kFloat);
+    static thread_local std::vector<int64_t> va, vb;          // scratch that keeps its capacity across calls
+    static thread_local std::vector<float> vw;
+    static thread_local std::vector<uint16_t> count;
+    va.resize((size_t)cap); vb.resize((size_t)cap); vw.resize((size_t)cap);
     int64_t out = 0;
     const char* err = nullptr;
     {
         pybind11::gil_scoped_release nogil;
-        int64_t *oa = pairs.data_ptr<int64_t>(), *ob = oa + cap;
-        float* ow = w.data_ptr<float>();
+        int64_t *oa = va.data(), *ob = vb.data();
+        float* ow = vw.data();
         const int64_t* p = ptr.data_ptr<int64_t>();
         const int64_t G = ptr.numel() - 1;
-        std::vector<uint16_t> count;
         for (int grp = 0; grp < 2 && !err; ++grp) {
             const at::Tensor& t = grp ? neg : pos;
             const int64_t E = t.size(1);
@@ -360,7 +425,7 @@ std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at:
                 while (e1 < E && s[e1] >= lo && s[e1] < hi) ++e1;             // this graph's run of pairs
                 if (e1 == e) continue;
                 if (n > 4096) { err = "hostdraw: graph too large for the pair table"; break; }
-                if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);
+                if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);      // (every touched entry is reset below: all zero between graphs)
                 for (int64_t k = e; k < e1; ++k) {
                     const int64_t x = s[k] - lo, y = d[k] - lo;
                     if (y < 0 || y >= n) { err = "hostdraw: pair crosses graphs"; break; }
@@ -383,8 +448,17 @@ std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at:
             if (!err && e != E) err = "hostdraw: pairs are not grouped by graph in batch order";
         }
     }
-    TORCH_CHECK(!err, err);
-    return {pairs.narrow(1, 0, out).contiguous(), w.narrow(0, 0, out).contiguous()};
+    if (err) {
+        std::fill(count.begin(), count.end(), 0);              // (a failed call may have left counts behind)
+        TORCH_CHECK(false, err);
+    }
+    at::Tensor pairs = at::empty({2, out}, at::kLong), w = at::empty({out}, at::kFloat);
+    if (out) {
+        std::memcpy(pairs.data_ptr<int64_t>(), va.data(), (size_t)out * sizeof(int64_t));
+        std::memcpy(pairs.data_ptr<int64_t>() + out, vb.data(), (size_t)out * sizeof(int64_t));
+        std::memcpy(w.data_ptr<float>(), vw.data(), (size_t)out * sizeof(float));
+    }
+    return {pairs, w};
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -395,5 +469,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("getstate", &PyRandom::getstate)
         .def("negative_edges", &PyRandom::negative_edges, "batched_negative_sampling(to_undirected(pos), batch, num_neg_samples=E) of a domain batch");
     m.def("merge_mirrored_pairs", &merge_mirrored_pairs, "unordered pairs + signed multiplicities of a domain's positive and negative pairs");
+    m.def("draw_step", &draw_step, "all index artefacts of one step in the reference's order, one call");
     m.def("draw_views", &draw_views, "two augmented views of every graph of a batch, as index arrays");
 }

@@ -228,6 +228,7 @@ class StepEngine:
         self._neg_native = None
         # score each unordered pair once (the scorer is symmetric in (src, dst)); GMP_LP_MERGE=0 keeps the reference's ordered list
         self.lp_merge = os.environ.get("GMP_LP_MERGE", "1") != "0"
+        self.fwd_split = os.environ.get("GMP_FWD_SPLIT", "1") != "0"
         for t in tasks:
             if t not in SUPPORTED_TASKS:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
@@ -455,6 +456,33 @@ class StepEngine:
         art: Dict[str, object] = {}
         host = {d: inp.host[d] for d in self.domains}
         H = hostdraw()
+        if H is not None and hasattr(H, "draw_step"):
+            # one native call for the whole step (GIL released once, generator locked once): the launcher thread's Python is not held up
+            # by sixteen hand-overs per step
+            if self._neg_native is None:
+                self._neg_native = H.PyRandom()
+                self._neg_native.setstate(torch.tensor(self.neg_rng.getstate()[1], dtype=torch.long))
+            kinds = [self.DRAWN_TASKS.index(t) for t in self.tasks if t in self.DRAWN_TASKS]
+            doms = inp.__dict__.get("_draw_args")
+            if doms is None:
+                doms = inp.__dict__["_draw_args"] = [_host_tensors(b) + (int(b.x.size(1)),) for b in host.values()]
+            res = iter(H.draw_step(kinds, doms, gen, self._neg_native))
+            for t in self.tasks:
+                if t not in self.DRAWN_TASKS:
+                    continue
+                row, art[t] = next(res), {}
+                for d, r in zip(host, row):
+                    if r is None:
+                        art[t][d] = None
+                    elif len(r) == 0:
+                        art[t][d] = _EMPTY_ART[t]()
+                    elif len(r) == 1:
+                        art[t][d] = r[0].numpy()
+                    else:
+                        art[t][d] = tuple(ViewArrays(*(x.numpy() for x in r[5 * v:5 * v + 3]),
+                                                     r[5 * v + 3].numpy().view(np.uint64) if r[5 * v + 3].numel() else None, r[5 * v + 4].numpy())
+                                          for v in range(2))
+            return art
         if H is not None:
             args = {d: _host_tensors(b) for d, b in host.items() if b.num_graphs}
         for t in self.tasks:
@@ -892,6 +920,9 @@ class StepEngine:
         e_all = np.concatenate(edges, axis=1)
         p.E = e_all.shape[1]
         p.max_seg = max(b - a for a, b in zip(seg_ptr[:-1], seg_ptr[1:]))
+        # the stacked forward runs as two row ranges on two streams (gnnmp_step.h fwd_split_*): cut at the segment boundary nearest N / 2
+        cut = min(range(1, p.S), key=lambda i: abs(2 * seg_ptr[i] - p.N)) if p.S > 1 and self.fwd_split else 0
+        p.fwd_split = (cut, seg_ptr[cut]) if cut and 0 < seg_ptr[cut] < p.N else (0, 0)
         if p.N > self.max_rows or p.E > self.max_edges or p.S > self.S_MAX:
             raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
                                f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
@@ -1715,6 +1746,7 @@ class StepEngine:
         D = self.domains
         d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
+        d.fwd_split_seg, d.fwd_split_row = p.fwd_split
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
         d.dp_exchange = int(self.grad_sync is not None or self.parts_beside_backward)     # publish when each part's gradients are final
         d.upload_on_aux = int(self.upload_on_aux)
@@ -1858,14 +1890,23 @@ class StepPrefetcher:
                     t0 = _t.perf_counter()
                     art = engine.draw(inp, gen)
                     self.draw_s += _t.perf_counter() - t0
-                    planq.put((inp, art))
+                    if one_stage:
+                        t0 = _t.perf_counter()
+                        item = (inp, (art, engine.plan(inp, art)))
+                        self.busy_s += _t.perf_counter() - t0
+                        self.q.put(item)
+                    else:
+                        planq.put((inp, art))
             except BaseException as e:           # surfaced on the consumer side
                 self._err = e
-            (self.q if engine.rng_mode == "device" else planq).put(None)
+            (self.q if engine.rng_mode == "device" or one_stage else planq).put(None)
 
-        # Host-order draws: a second stage lays the segments out (engine.plan: numpy, no RNG, no engine state), so the draws of step
-        # t + 1 (native code, GIL released) run beside the layout of step t -- together they were 1.3 of a 1.57 ms step.
+        # GMP_PREFETCH_STAGES=2: a second thread lays the segments out (engine.plan: numpy, no RNG, no engine state) while this one
+        # draws the next step (native, GIL released).  Measured equal to one thread at today's step time (1.51 against 1.50 ms: the
+        # launcher never waits for either) and noisier -- three Python threads share one GIL -- so one thread is the default; the
+        # split is the headroom for a faster device half (draws 0.8 + layout 0.6 ms busy per 1.5 ms step).
         planq: "queue.Queue" = queue.Queue(maxsize=2)
+        one_stage = os.environ.get("GMP_PREFETCH_STAGES", "1") != "2"
 
         def layout() -> None:
             import time as _t
@@ -1883,9 +1924,12 @@ class StepPrefetcher:
                 self._err = e
             self.q.put(None)
 
+        if os.environ.get("GMP_SWITCH_INTERVAL"):
+            import sys
+            sys.setswitchinterval(float(os.environ["GMP_SWITCH_INTERVAL"]))
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
-        if engine.rng_mode != "device":
+        if engine.rng_mode != "device" and not one_stage:
             self.plan_thread = threading.Thread(target=layout, daemon=True)
             self.plan_thread.start()
 

@@ -80,6 +80,9 @@ int gmp_csr_build_segmented(const int64_t* edge_index, int64_t num_nodes, int64_
  * ------------------------------------------------------------------------- */
 int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, const int32_t* col, const float* eps,
                           float* out, int64_t num_nodes, int feat, gmp_stream_t stream);
+/* rows [row0, row1) of gmp_gin_aggregate_fwd (x, rowptr, col in the whole batch's numbering; cache-resident sizes) */
+int gmp_gin_aggregate_fwd_rows(const float* x, const int32_t* rowptr, const int32_t* col, const float* eps, float* out,
+                               int64_t row0, int64_t row1, int feat, gmp_stream_t stream);
 size_t gmp_gin_aggregate_bwd_workspace_bytes(int64_t num_nodes, int feat);
 int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t, const int32_t* col_t, const float* eps,
                           const float* x, float* g_x, float* g_eps, int64_t num_nodes, int feat,

@@ -105,6 +105,11 @@ typedef struct {
        workgroup per (domain, orientation) -- gmp_csr_build_segmented over rows [0, lp_rows_end) -- instead of one workgroup for all
        ~30 k edges (0.49 ms).  lp_S = 0: whole-batch build. */
     const int32_t *lp_seg_ptr, *lp_seg_eptr; int32_t lp_S; int64_t lp_max_seg_rows, lp_max_seg_edges, lp_rows_end;
+    /* Stacked forward in two halves: segments [0, fwd_split_seg) = rows [0, fwd_split_row) on main, the rest on one of the task
+       streams (idle until the heads), so one half's latency-bound BatchNorm / aggregation launches run beside the other half's GEMMs.
+       Segments are independent through the backbone (per-segment statistics, block-diagonal adjacency), every kernel is
+       element-wise identical under a row split: the result is bit-identical to the unsplit forward.  0 = one pass on main. */
+    int32_t fwd_split_seg, fwd_split_row;
     /* parameters and per-task gradients */
     float* flat; int64_t P; float* task_grads;
     /* encoders */

@@ -109,6 +109,9 @@ def test_linear_bn_backward_input(S, lo, hi, K, N, relu):
         if e == a:
             assert sums[s].abs().max().item() == 0
             continue
+        if e - a == 1:                      # one row: xhat = 0 and the gradient cancels (torch refuses the case)
+            assert g_x[a:e].abs().max().item() < 1e-4 * scale
+            continue
         xs = x[a:e].double().requires_grad_(True)
         yy = torch.nn.functional.batch_norm(xs, None, None, gam.double(), bet.double(), True, 0.1, 1e-5)
         if relu:
