@@ -74,9 +74,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # process, so the figure is a constant -- tied to the source it was measured on: `roofline.traffic` is reported only while
 # csrc/aggregate.hip still hashes to PMC_SOURCE_SHA16 (and the rung is PMC_SHAPE), null otherwise (re-measure: profiles/README.md).
 PMC_SHAPE = (2146816, 8068480)
-PMC_TRAFFIC_BYTES = int((1229841.7 * 2 + 2146902.4) * 1024)     # profiles/r02_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
-PMC_TRAFFIC_BYTES_BWD = int((2689442.0 * 2 + 2167694.2) * 1024) # same file, backward with the eps row products (1.16 x algorithmic)
-PMC_SOURCE_SHA16 = "094d745b096dd17c"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernels
+PMC_TRAFFIC_BYTES = int((1229083.6 * 2 + 2146899.6) * 1024)     # profiles/r02b_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
+PMC_TRAFFIC_BYTES_BWD = int((2689371.2 * 2 + 2167702.9) * 1024) # same file, backward with the eps row products (1.16 x algorithmic)
+PMC_SOURCE_SHA16 = "238f502693b22f8b"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernels
 
 
 def pmc_traffic(shape, backward: bool = False):
