@@ -409,8 +409,10 @@ int launch_pipe_tile(int tile, const GemmArgs& g, int64_t rows, int z, hipStream
     const int deep = e ? atoi(e) : 0;
     switch (tile) {
         case 0: return launch_pipe_cfg<2, 2, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
-        case 1: return launch_pipe_cfg<1, 2, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
-        case 2: return launch_pipe_cfg<2, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+        case 1: return deep == 3 ? launch_pipe_cfg<1, 2, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
+                                 : launch_pipe_cfg<1, 2, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+        case 2: return deep == 3 ? launch_pipe_cfg<2, 1, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
+                                 : launch_pipe_cfg<2, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
         default: return deep == 3 ? launch_pipe_cfg<1, 1, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
                                   : launch_pipe_cfg<1, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
     }
