@@ -49,6 +49,18 @@ def lib() -> C.CDLL:
 p, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
 
+class AugMasksJob(C.Structure):          # gmp_aug_masks_job (include/gnnmp.h)
+    _fields_ = [("ptr", C.c_void_p), ("out_ptr", C.c_void_p), ("num_graphs", C.c_int32), ("stream_id", C.c_uint32), ("out_idx", C.c_void_p)]
+
+
+class AugViewsJob(C.Structure):          # gmp_aug_views_job
+    _fields_ = [("ptr", C.c_void_p), ("eptr", C.c_void_p), ("edge_index", C.c_void_p), ("num_nodes", C.c_int64), ("num_edges", C.c_int64),
+                ("view_ptr", C.c_void_p), ("num_graphs", C.c_int32), ("num_features", C.c_int32), ("stream_id", C.c_uint32),
+                ("rows1", C.c_void_p), ("rows2", C.c_void_p), ("rowmask1", C.c_void_p), ("rowmask2", C.c_void_p), ("edges1", C.c_void_p),
+                ("edges2", C.c_void_p), ("edge_capacity", C.c_int64), ("common1", C.c_void_p), ("common2", C.c_void_p), ("counts", C.c_void_p),
+                ("totals_and_flags", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class BnConfig(C.Structure):
     _fields_ = [("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float), ("momentum", C.c_float),
                 ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint32)]
@@ -115,6 +127,8 @@ _SIGS: Dict[str, tuple] = {
     "gmp_gate_set_timeout": (C.c_int, [C.c_double]),
     "gmp_aug_workspace_bytes": (sz, [i64, i64, i32]),
     "gmp_aug_node_masks": (C.c_int, [p, p, i32, i64, C.c_uint64, C.c_uint32, p, p]),
+    "gmp_aug_node_masks_batch": (C.c_int, [C.POINTER(AugMasksJob), i32, i64, C.c_uint64, p]),
+    "gmp_aug_two_views_batch": (C.c_int, [C.POINTER(AugViewsJob), i32, i64, i64, C.c_uint64, p]),
     "gmp_aug_two_views": (C.c_int, [p, p, p, i64, i64, p, i32, i64, i64, i32, C.c_uint64, C.c_uint32, p, p, p, p, p, p, i64, p, p, p, p, p, sz, p]),
     "gmp_upload": (C.c_int, [i32, p, p, p, p]),
     "gmp_segments_pack": (C.c_int, [p, p, p, i32, i64, p]),

@@ -37,11 +37,10 @@ __device__ __forceinline__ int drop_count(int n, double rate) {                 
 }
 
 // ---- node-feature-masking indices: per graph with n >= 3 the max(1, int(.15 n)) nodes of smallest key, ascending -------------------
-__global__ __launch_bounds__(AB) void nfm_masks_kernel(const int64_t* __restrict__ ptr, const int64_t* __restrict__ out_ptr, uint64_t seed,
-                                                       uint32_t stream, int64_t* __restrict__ out) {
+__device__ __forceinline__ void nfm_masks_body(const int64_t* __restrict__ ptr, const int64_t* __restrict__ out_ptr, uint64_t seed,
+                                               uint32_t stream, int64_t* __restrict__ out, const int g) {
     __shared__ uint32_t keys[MAX_NODES];
     __shared__ uint8_t chosen[MAX_NODES];
-    const int g = blockIdx.x;
     const int64_t s = ptr[g];
     const int n = (int)(ptr[g + 1] - s);
     if (n < 3) return;
@@ -61,6 +60,25 @@ __global__ __launch_bounds__(AB) void nfm_masks_kernel(const int64_t* __restrict
         for (int j = 0; j < i; ++j) before += chosen[j];
         out[out_ptr[g] + before] = s + i;
     }
+}
+__global__ __launch_bounds__(AB) void nfm_masks_kernel(const int64_t* __restrict__ ptr, const int64_t* __restrict__ out_ptr, uint64_t seed,
+                                                       uint32_t stream, int64_t* __restrict__ out) {
+    nfm_masks_body(ptr, out_ptr, seed, stream, out, blockIdx.x);
+}
+
+// Batched forms: ONE launch for all the (task, domain) jobs of a step -- the jobs ride in the kernel arguments, a workgroup finds its job
+// from the running graph counts.  Same arithmetic, same keys: results identical to the per-job launches.
+constexpr int AUG_MAXJ = 8;
+struct MaskJob { const int64_t* ptr; const int64_t* out_ptr; int64_t* out; uint32_t stream; };
+struct MaskBatch { MaskJob job[AUG_MAXJ]; int first[AUG_MAXJ + 1]; int count; uint64_t seed; };
+__device__ __forceinline__ int job_of(const int* first, int count, int b) {
+    int j = 0;
+    while (j + 1 < count && b >= first[j + 1]) ++j;
+    return j;
+}
+__global__ __launch_bounds__(AB) void nfm_masks_batch_kernel(const MaskBatch b) {
+    const int j = job_of(b.first, b.count, blockIdx.x);
+    nfm_masks_body(b.job[j].ptr, b.job[j].out_ptr, b.seed, b.job[j].stream, b.job[j].out, blockIdx.x - b.first[j]);
 }
 
 struct ViewArgs {
@@ -87,8 +105,7 @@ struct ViewArgs {
 // LDS is sized per launch from the batch's largest graph (ncap nodes, ecap edges; a few KB for TUDataset graphs): these blocks run
 // beside the step's GEMMs, whose 64 KB blocks leave little LDS free on a CU -- a 56 KB static footprint waited for a GEMM block to
 // retire before it could start (58 us per launch in the step against ~10 alone)
-__global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a, int ncap, int ecap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+__device__ __forceinline__ void two_views_body(const ViewArgs& a, const int ncap, const int ecap, const int g, unsigned char* dyn) {
     unsigned long long* const s_bits_p = reinterpret_cast<unsigned long long*>(dyn);
     int* const s_cnt = reinterpret_cast<int*>(dyn + 8);
     uint32_t* const keys = reinterpret_cast<uint32_t*>(dyn + 32);
@@ -98,7 +115,7 @@ __global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a, int nca
     uint8_t* const s_eflag = reinterpret_cast<uint8_t*>(newid1 + ncap);
     uint16_t* const newid[2] = {newid0, newid1};
 #define s_bits (*s_bits_p)
-    const int g = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int64_t s = a.ptr[g], es = a.eptr[g];
     const int n = (int)(a.ptr[g + 1] - s), ne = (int)(a.eptr[g + 1] - es);
     const int keep_n = n >= 3 ? n - drop_count(n, 0.2) : n;
@@ -228,8 +245,8 @@ struct EmitArgs {
 };
 
 // slots -> final offsets (exclusive scan of the per-graph counts), graph-local new ids -> view numbering (+ vptr[g])
-__global__ __launch_bounds__(AB) void emit_views_kernel(const EmitArgs a) {
-    const int g = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void emit_views_body(const EmitArgs& a, const int g) {
+    const int t = threadIdx.x;
     for (int v = 0; v < 2; ++v) {
         int64_t off = 0;
         for (int q = 0; q < g; ++q) off += a.edge_count[v][q];
@@ -256,6 +273,22 @@ __global__ __launch_bounds__(AB) void emit_views_kernel(const EmitArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(AB) void emit_views_kernel(const EmitArgs a) { emit_views_body(a, blockIdx.x); }
+__global__ __launch_bounds__(AB) void two_views_kernel(const ViewArgs a, int ncap, int ecap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    two_views_body(a, ncap, ecap, blockIdx.x, dyn);
+}
+struct ViewBatch { ViewArgs job[AUG_MAXJ]; int first[AUG_MAXJ + 1]; int count; };
+struct EmitBatch { EmitArgs job[AUG_MAXJ]; int first[AUG_MAXJ + 1]; int count; };
+__global__ __launch_bounds__(AB) void two_views_batch_kernel(const ViewBatch b, int ncap, int ecap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int j = job_of(b.first, b.count, blockIdx.x);
+    two_views_body(b.job[j], ncap, ecap, blockIdx.x - b.first[j], dyn);
+}
+__global__ __launch_bounds__(AB) void emit_views_batch_kernel(const EmitBatch b) {
+    const int j = job_of(b.first, b.count, blockIdx.x);
+    emit_views_body(b.job[j], blockIdx.x - b.first[j]);
+}
 
 }  // namespace
 
@@ -274,43 +307,135 @@ extern "C" int gmp_aug_node_masks(const int64_t* ptr, const int64_t* out_ptr, in
     return gmp::check_launch("nfm_masks_kernel");
 }
 
+namespace {
+struct ViewsCall {            // plain-argument form of one two-views job (what both entry points validate and turn into kernel arguments)
+    const int64_t *ptr, *eptr, *edge_index;
+    int64_t num_nodes, num_edges;
+    const int64_t* view_ptr;
+    int num_graphs, num_features;
+    uint32_t stream_id;
+    int64_t *rows1, *rows2;
+    uint64_t *rowmask1, *rowmask2;
+    int64_t *edges1, *edges2;
+    int64_t edge_capacity;
+    int64_t *common1, *common2;
+    int32_t *counts, *totals_and_flags;
+    void* workspace;
+    size_t workspace_bytes;
+};
+int views_check(const ViewsCall& c, int64_t max_graph_nodes, int64_t max_graph_edges) {
+    if (c.num_graphs < 0 || c.num_edges < 0 || c.num_features < 0 || c.num_features > 64)
+        return gmp::fail(GMP_ERR_ARG, "aug_two_views: bad sizes (attribute masks are 64-bit column sets)");
+    if (c.num_graphs == 0) return GMP_OK;
+    if (!c.ptr || !c.eptr || !c.view_ptr || !c.rows1 || !c.rows2 || !c.rowmask1 || !c.rowmask2 || !c.edges1 || !c.edges2 || !c.common1 || !c.common2 ||
+        !c.counts || !c.totals_and_flags || (c.num_edges > 0 && !c.edge_index))
+        return gmp::fail(GMP_ERR_ARG, "aug_two_views: null pointer");
+    if (max_graph_nodes > MAX_NODES) return gmp::fail(GMP_ERR_UNSUPPORTED, "aug_two_views: a graph of %lld nodes (limit %d)", (long long)max_graph_nodes, MAX_NODES);
+    if (c.edge_capacity < c.num_edges) return gmp::fail(GMP_ERR_ARG, "aug_two_views: edge capacity below the batch's edge count");
+    if (max_graph_edges > 8192) return gmp::fail(GMP_ERR_UNSUPPORTED, "aug_two_views: a graph of %lld edges (limit 8192)", (long long)max_graph_edges);
+    if (!c.workspace || c.workspace_bytes < gmp_aug_workspace_bytes(c.num_nodes, c.num_edges, c.num_graphs)) return gmp::fail(GMP_ERR_WORKSPACE, "aug_two_views: workspace");
+    return GMP_OK;
+}
+void views_args(const ViewsCall& c, uint64_t seed, ViewArgs* ap, EmitArgs* ep) {
+    int64_t* w = (int64_t*)c.workspace;
+    ViewArgs a{};
+    a.ptr = c.ptr; a.eptr = c.eptr; a.src = c.edge_index; a.dst = c.edge_index ? c.edge_index + c.num_edges : nullptr; a.vptr = c.view_ptr;
+    a.G = c.num_graphs; a.F = c.num_features; a.seed = seed; a.stream = c.stream_id;
+    a.rows[0] = c.rows1; a.rows[1] = c.rows2; a.rowmask[0] = c.rowmask1; a.rowmask[1] = c.rowmask2;
+    a.slot_src[0] = w; a.slot_dst[0] = w + c.num_edges; a.slot_src[1] = w + 2 * c.num_edges; a.slot_dst[1] = w + 3 * c.num_edges;
+    a.slot_common[0] = w + 4 * c.num_edges; a.slot_common[1] = a.slot_common[0] + c.num_nodes;
+    a.ekey = (uint32_t*)(a.slot_common[1] + c.num_nodes);
+    a.eflag = (uint8_t*)(a.ekey + c.num_edges);
+    a.edge_count[0] = c.counts; a.edge_count[1] = c.counts + c.num_graphs; a.common_count = c.counts + 2 * c.num_graphs;
+    a.mask_flag[0] = c.counts + 3 * c.num_graphs; a.mask_flag[1] = c.counts + 4 * c.num_graphs;
+    EmitArgs e{};
+    e.ptr = c.ptr; e.eptr = c.eptr; e.vptr = c.view_ptr; e.G = c.num_graphs;
+    for (int v = 0; v < 2; ++v) { e.slot_src[v] = a.slot_src[v]; e.slot_dst[v] = a.slot_dst[v]; e.slot_common[v] = a.slot_common[v]; e.edge_count[v] = a.edge_count[v]; }
+    e.common_count = a.common_count;
+    e.mask_flag[0] = a.mask_flag[0]; e.mask_flag[1] = a.mask_flag[1];
+    e.edges[0] = c.edges1; e.edges[1] = c.edges2; e.ecap = c.edge_capacity; e.common[0] = c.common1; e.common[1] = c.common2; e.totals = c.totals_and_flags;
+    *ap = a; *ep = e;
+}
+size_t views_lds(int64_t max_graph_nodes, int64_t max_graph_edges, int* ncap, int* ecap) {
+    *ncap = (int)((max_graph_nodes + 63) / 64 * 64);
+    *ecap = max_graph_edges <= EDGES_LDS ? (int)((max_graph_edges + 63) / 64 * 64) : 0;
+    return 32 + (size_t)*ncap * 4 + (size_t)*ecap * 4 + (size_t)*ncap * 4 + (size_t)*ecap + 64;
+}
+}  // namespace
+
 extern "C" int gmp_aug_two_views(const int64_t* ptr, const int64_t* eptr, const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
                                  const int64_t* view_ptr, int num_graphs, int64_t max_graph_nodes, int64_t max_graph_edges, int num_features, uint64_t seed, uint32_t stream_id,
                                  int64_t* rows1, int64_t* rows2, uint64_t* rowmask1, uint64_t* rowmask2, int64_t* edges1, int64_t* edges2,
                                  int64_t edge_capacity, int64_t* common1, int64_t* common2, int32_t* counts, int32_t* totals_and_flags,
                                  void* workspace, size_t workspace_bytes, gmp_stream_t stream) {
-    if (num_graphs < 0 || num_edges < 0 || num_features < 0 || num_features > 64)
-        return gmp::fail(GMP_ERR_ARG, "aug_two_views: bad sizes (attribute masks are 64-bit column sets)");
+    const ViewsCall c{ptr, eptr, edge_index, num_nodes, num_edges, view_ptr, num_graphs, num_features, stream_id, rows1, rows2, rowmask1, rowmask2,
+                      edges1, edges2, edge_capacity, common1, common2, counts, totals_and_flags, workspace, workspace_bytes};
+    if (int rc = views_check(c, max_graph_nodes, max_graph_edges)) return rc;
     if (num_graphs == 0) return GMP_OK;
-    if (!ptr || !eptr || !view_ptr || !rows1 || !rows2 || !rowmask1 || !rowmask2 || !edges1 || !edges2 || !common1 || !common2 || !counts ||
-        !totals_and_flags || (num_edges > 0 && !edge_index))
-        return gmp::fail(GMP_ERR_ARG, "aug_two_views: null pointer");
-    if (max_graph_nodes > MAX_NODES) return gmp::fail(GMP_ERR_UNSUPPORTED, "aug_two_views: a graph of %lld nodes (limit %d)", (long long)max_graph_nodes, MAX_NODES);
-    if (edge_capacity < num_edges) return gmp::fail(GMP_ERR_ARG, "aug_two_views: edge capacity below the batch's edge count");
+    ViewArgs a;
+    EmitArgs e;
+    views_args(c, seed, &a, &e);
+    int ncap, ecap;
+    const size_t lds = views_lds(max_graph_nodes, max_graph_edges, &ncap, &ecap);
     hipStream_t st = (hipStream_t)stream;
-    if (max_graph_edges > 8192) return gmp::fail(GMP_ERR_UNSUPPORTED, "aug_two_views: a graph of %lld edges (limit 8192)", (long long)max_graph_edges);
-    if (!workspace || workspace_bytes < gmp_aug_workspace_bytes(num_nodes, num_edges, num_graphs)) return gmp::fail(GMP_ERR_WORKSPACE, "aug_two_views: workspace");
-    int64_t* w = (int64_t*)workspace;
-    ViewArgs a{};
-    a.ptr = ptr; a.eptr = eptr; a.src = edge_index; a.dst = edge_index ? edge_index + num_edges : nullptr; a.vptr = view_ptr;
-    a.G = num_graphs; a.F = num_features; a.seed = seed; a.stream = stream_id;
-    a.rows[0] = rows1; a.rows[1] = rows2; a.rowmask[0] = rowmask1; a.rowmask[1] = rowmask2;
-    a.slot_src[0] = w; a.slot_dst[0] = w + num_edges; a.slot_src[1] = w + 2 * num_edges; a.slot_dst[1] = w + 3 * num_edges;
-    a.slot_common[0] = w + 4 * num_edges; a.slot_common[1] = a.slot_common[0] + num_nodes;
-    a.ekey = (uint32_t*)(a.slot_common[1] + num_nodes);
-    a.eflag = (uint8_t*)(a.ekey + num_edges);
-    a.edge_count[0] = counts; a.edge_count[1] = counts + num_graphs; a.common_count = counts + 2 * num_graphs;
-    a.mask_flag[0] = counts + 3 * num_graphs; a.mask_flag[1] = counts + 4 * num_graphs;
-    const int ncap = (int)((max_graph_nodes + 63) / 64 * 64);
-    const int ecap = max_graph_edges <= EDGES_LDS ? (int)((max_graph_edges + 63) / 64 * 64) : 0;
-    const size_t lds = 32 + (size_t)ncap * 4 + (size_t)ecap * 4 + (size_t)ncap * 4 + (size_t)ecap + 64;
     hipLaunchKernelGGL(two_views_kernel, dim3(num_graphs), dim3(AB), lds, st, a, ncap, ecap);
-    EmitArgs e{};
-    e.ptr = ptr; e.eptr = eptr; e.vptr = view_ptr; e.G = num_graphs;
-    for (int v = 0; v < 2; ++v) { e.slot_src[v] = a.slot_src[v]; e.slot_dst[v] = a.slot_dst[v]; e.slot_common[v] = a.slot_common[v]; e.edge_count[v] = a.edge_count[v]; }
-    e.common_count = a.common_count;
-    e.mask_flag[0] = a.mask_flag[0]; e.mask_flag[1] = a.mask_flag[1];
-    e.edges[0] = edges1; e.edges[1] = edges2; e.ecap = edge_capacity; e.common[0] = common1; e.common[1] = common2; e.totals = totals_and_flags;
     hipLaunchKernelGGL(emit_views_kernel, dim3(num_graphs), dim3(AB), 0, st, e);
     return gmp::check_launch("aug_two_views kernels");
+}
+
+// All the two-views jobs of a step -- one per contrastive (task, domain) pair -- in TWO launches (build, emit) instead of two per
+// job: the draws ride the aux stream beside a running step, where sixteen 10-60 us launches per step cost it 0.3 ms.
+extern "C" int gmp_aug_two_views_batch(const gmp_aug_views_job* jobs, int count, int64_t max_graph_nodes, int64_t max_graph_edges, uint64_t seed,
+                                       gmp_stream_t stream) {
+    if (count < 0 || (count > 0 && !jobs)) return gmp::fail(GMP_ERR_ARG, "aug_two_views_batch: bad job list");
+    int ncap, ecap;
+    const size_t lds = views_lds(max_graph_nodes, max_graph_edges, &ncap, &ecap);
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < count;) {
+        ViewBatch vb{};
+        EmitBatch eb{};
+        int n = 0, blocks = 0;
+        for (; j0 < count && n < AUG_MAXJ; ++j0) {
+            const gmp_aug_views_job& q = jobs[j0];
+            const ViewsCall c{q.ptr, q.eptr, q.edge_index, q.num_nodes, q.num_edges, q.view_ptr, q.num_graphs, q.num_features, q.stream_id, q.rows1, q.rows2,
+                              q.rowmask1, q.rowmask2, q.edges1, q.edges2, q.edge_capacity, q.common1, q.common2, q.counts, q.totals_and_flags, q.workspace,
+                              q.workspace_bytes};
+            if (int rc = views_check(c, max_graph_nodes, max_graph_edges)) return rc;
+            if (c.num_graphs == 0) continue;
+            views_args(c, seed, &vb.job[n], &eb.job[n]);
+            vb.first[n] = eb.first[n] = blocks;
+            blocks += c.num_graphs;
+            ++n;
+        }
+        if (n == 0) continue;
+        vb.first[n] = eb.first[n] = blocks;
+        vb.count = eb.count = n;
+        hipLaunchKernelGGL(two_views_batch_kernel, dim3(blocks), dim3(AB), lds, st, vb, ncap, ecap);
+        hipLaunchKernelGGL(emit_views_batch_kernel, dim3(blocks), dim3(AB), 0, st, eb);
+    }
+    return gmp::check_launch("aug_two_views_batch kernels");
+}
+
+extern "C" int gmp_aug_node_masks_batch(const gmp_aug_masks_job* jobs, int count, int64_t max_graph_nodes, uint64_t seed, gmp_stream_t stream) {
+    if (count < 0 || (count > 0 && !jobs)) return gmp::fail(GMP_ERR_ARG, "aug_node_masks_batch: bad job list");
+    if (max_graph_nodes > MAX_NODES) return gmp::fail(GMP_ERR_UNSUPPORTED, "aug_node_masks_batch: a graph of %lld nodes (limit %d)", (long long)max_graph_nodes, MAX_NODES);
+    for (int j0 = 0; j0 < count;) {
+        MaskBatch mb{};
+        int n = 0, blocks = 0;
+        for (; j0 < count && n < AUG_MAXJ; ++j0) {
+            const gmp_aug_masks_job& q = jobs[j0];
+            if (q.num_graphs < 0 || (q.num_graphs > 0 && (!q.ptr || !q.out_ptr || !q.out_idx))) return gmp::fail(GMP_ERR_ARG, "aug_node_masks_batch: bad job");
+            if (q.num_graphs == 0) continue;
+            mb.job[n] = MaskJob{q.ptr, q.out_ptr, q.out_idx, q.stream_id};
+            mb.first[n] = blocks;
+            blocks += q.num_graphs;
+            ++n;
+        }
+        if (n == 0) continue;
+        mb.first[n] = blocks;
+        mb.count = n;
+        mb.seed = seed;
+        hipLaunchKernelGGL(nfm_masks_batch_kernel, dim3(blocks), dim3(AB), 0, (hipStream_t)stream, mb);
+    }
+    return gmp::check_launch("nfm_masks_batch_kernel");
 }

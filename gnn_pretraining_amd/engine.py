@@ -636,27 +636,39 @@ class StepEngine:
         base = slot["dev"].data_ptr()
         seed = (self.seed * 1000003 + 0x5bd1e995 * (k + 1)) & (2 ** 64 - 1)
         if True:
+            # every (task, domain) job of the step in three launches (masks | views | emit): on the aux stream beside a running step the
+            # twenty per-job launches cost that step 0.3 ms
+            mjobs, vjobs, nmax_all, emax_all, ws_need = [], [], 1, 0, 0
+            for (t, d, o) in lay:
+                hb = inp.host[d]
+                nmax_all = max(nmax_all, max(int(b - a) for a, b in zip(hb.ptr_host[:-1], hb.ptr_host[1:])))
+                if t != "node_feat_mask":
+                    emax_all = max([emax_all] + [int(b - a) for a, b in zip(hb.edge_ptr_host[:-1], hb.edge_ptr_host[1:])])
+                    o["ws_off"], o["ws_bytes"] = ws_need, (lib.gmp_aug_workspace_bytes(hb.num_nodes, o["E"], hb.num_graphs) + 255) // 256 * 256
+                    ws_need += o["ws_bytes"]
+            if ws_need and (self._draw_ws is None or self._draw_ws.numel() < ws_need):
+                # (kernels of earlier tickets may still be using the old one on the aux stream: keep it alive.  One region per JOB -- the
+                # jobs of a ticket run concurrently; tickets follow each other on the aux stream and share the regions)
+                self._draw_graveyard.append(self._draw_ws)
+                self._draw_ws = torch.empty(max(2 * ws_need, 4 * lib.gmp_aug_workspace_bytes(self.max_rows, self.max_edges, 1024)),
+                                            dtype=torch.uint8, device=self.device)
+            ws_base = self._draw_ws.data_ptr() if ws_need else 0
             for (t, d, o) in lay:
                 ptr, eptr, ei, vptr, optr, _, _ = inp.dev_graph(d)
                 hb = inp.host[d]
                 sid = 16 * self.tasks.index(t) + 2 * self.domains.index(d) * len(self.tasks) * 16
-                nmax = max(int(b - a) for a, b in zip(hb.ptr_host[:-1], hb.ptr_host[1:]))
                 if t == "node_feat_mask":
                     if o["m"]:
-                        self._chk(lib.gmp_aug_node_masks(ptr.data_ptr(), optr.data_ptr(), hb.num_graphs, nmax, seed, sid, base + o["idx"], aux), "aug_node_masks")
+                        mjobs.append(L.AugMasksJob(ptr.data_ptr(), optr.data_ptr(), hb.num_graphs, sid, base + o["idx"]))
                 else:
-                    need = lib.gmp_aug_workspace_bytes(hb.num_nodes, o["E"], hb.num_graphs)
-                    if self._draw_ws is None or self._draw_ws.numel() < need:
-                        # (kernels of earlier tickets may still be using the old one on the aux stream: keep it alive)
-                        self._draw_graveyard.append(self._draw_ws)
-                        self._draw_ws = torch.empty(max(2 * need, lib.gmp_aug_workspace_bytes(self.max_rows, self.max_edges, 1024)),
-                                                    dtype=torch.uint8, device=self.device)
-                    emax = max([int(b - a) for a, b in zip(hb.edge_ptr_host[:-1], hb.edge_ptr_host[1:])] + [0])
-                    self._chk(lib.gmp_aug_two_views(ptr.data_ptr(), eptr.data_ptr(), ei.data_ptr(), hb.num_nodes, o["E"], vptr.data_ptr(), hb.num_graphs,
-                                                    nmax, emax, int(hb.x.size(1)), seed, sid, base + o["rows"][0], base + o["rows"][1],
-                                                    base + o["mask"][0], base + o["mask"][1], base + o["edges"][0], base + o["edges"][1], max(o["E"], 1),
-                                                    base + o["common"][0], base + o["common"][1], base + o["counts"], base + o["totals"],
-                                                    self._draw_ws.data_ptr(), self._draw_ws.numel(), aux), "aug_two_views")
+                    vjobs.append(L.AugViewsJob(ptr.data_ptr(), eptr.data_ptr(), ei.data_ptr(), hb.num_nodes, o["E"], vptr.data_ptr(), hb.num_graphs,
+                                               int(hb.x.size(1)), sid, base + o["rows"][0], base + o["rows"][1], base + o["mask"][0], base + o["mask"][1],
+                                               base + o["edges"][0], base + o["edges"][1], max(o["E"], 1), base + o["common"][0], base + o["common"][1],
+                                               base + o["counts"], base + o["totals"], ws_base + o["ws_off"], o["ws_bytes"]))
+            if mjobs:
+                self._chk(lib.gmp_aug_node_masks_batch((L.AugMasksJob * len(mjobs))(*mjobs), len(mjobs), nmax_all, seed, aux), "aug_node_masks_batch")
+            if vjobs:
+                self._chk(lib.gmp_aug_two_views_batch((L.AugViewsJob * len(vjobs))(*vjobs), len(vjobs), nmax_all, emax_all, seed, aux), "aug_two_views_batch")
             src = (C.c_void_p * 1)(base)
             dst = (C.c_void_p * 1)(slot["pin"].data_ptr())
             self._chk(lib.gmp_upload(1, src, dst, (C.c_int64 * 1)((total + 15) // 16 * 16), aux), "draw results -> pinned host")

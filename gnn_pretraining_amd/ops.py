@@ -550,3 +550,60 @@ def aug_two_views(ptr: Tensor, eptr: Tensor, edge_index: Tensor, ptr_host, eptr_
                                 _ptr(edges[0]), _ptr(edges[1]), max(E, 1), _ptr(common[0]), _ptr(common[1]), _ptr(counts), _ptr(totals),
                                 _ptr(ws), ws.numel(), _stream(ptr)), "gmp_aug_two_views")
     return DeviceViews(rows, masks, edges, common, counts, totals, vp)
+
+
+def aug_node_masks_batch(jobs, seed: int):
+    """gmp_aug_node_masks for several domain batches in ONE launch.  jobs: [(ptr, ptr_host, stream_id)]; returns a list of index tensors
+    identical to aug_node_masks(ptr, ptr_host, seed, stream_id) per job."""
+    outs, cjobs, keep, nmax = [], [], [], 1
+    for ptr, ptr_host, sid in jobs:
+        _need(ptr, torch.int64, "ptr", 1)
+        _, masked = view_sizes(ptr_host)
+        off = [0]
+        for m in masked:
+            off.append(off[-1] + m)
+        out = torch.empty(off[-1], dtype=torch.int64, device=ptr.device)
+        outs.append(out)
+        if off[-1] == 0:
+            continue
+        out_ptr = torch.tensor(off, dtype=torch.int64).to(ptr.device)
+        keep.append(out_ptr)
+        nmax = max(nmax, max(int(b - a) for a, b in zip(ptr_host[:-1], ptr_host[1:])))
+        cjobs.append(L.AugMasksJob(_ptr(ptr), _ptr(out_ptr), len(ptr_host) - 1, sid & 0xffffffff, _ptr(out)))
+    if cjobs:
+        L.check(L.lib().gmp_aug_node_masks_batch((L.AugMasksJob * len(cjobs))(*cjobs), len(cjobs), nmax, seed & (2 ** 64 - 1), _stream(jobs[0][0])),
+                "gmp_aug_node_masks_batch")
+    return outs
+
+
+def aug_two_views_batch(jobs, seed: int):
+    """gmp_aug_two_views for several domain batches in TWO launches.  jobs: [(ptr, eptr, edge_index, ptr_host, eptr_host, num_features,
+    stream_id)]; returns a list of DeviceViews identical to aug_two_views(..., seed, stream_id) per job."""
+    res, cjobs, keep, nmax, emax = [], [], [], 1, 0
+    l = L.lib()
+    for ptr, eptr, edge_index, ptr_host, eptr_host, F, sid in jobs:
+        dev, G = ptr.device, len(ptr_host) - 1
+        N, E = int(ptr_host[-1]), int(edge_index.size(1))
+        kept, _ = view_sizes(ptr_host)
+        vp = [0]
+        for k in kept:
+            vp.append(vp[-1] + k)
+        vptr = torch.tensor(vp, dtype=torch.int64).to(dev)
+        mk = lambda n, dt=torch.int64: torch.empty(n, dtype=dt, device=dev)
+        rows, masks = (mk(vp[-1]), mk(vp[-1])), (mk(vp[-1]), mk(vp[-1]))
+        edges, common = (mk(2 * max(E, 1)).view(2, -1), mk(2 * max(E, 1)).view(2, -1)), (mk(vp[-1]), mk(vp[-1]))
+        counts, totals = mk(5 * max(G, 1), torch.int32), mk(5, torch.int32)
+        ws = _ws(l.gmp_aug_workspace_bytes(N, E, G), dev).clone()          # (one region per job: the jobs of a launch run concurrently)
+        ei = edge_index.contiguous()
+        keep += [vptr, ws, ei]
+        nmax = max([nmax] + [int(b - a) for a, b in zip(ptr_host[:-1], ptr_host[1:])])
+        emax = max([emax] + [int(b - a) for a, b in zip(eptr_host[:-1], eptr_host[1:])])
+        cjobs.append(L.AugViewsJob(_ptr(ptr), _ptr(eptr), _ptr(ei), N, E, _ptr(vptr), G, F, sid & 0xffffffff, _ptr(rows[0]), _ptr(rows[1]),
+                                   _ptr(masks[0]), _ptr(masks[1]), _ptr(edges[0]), _ptr(edges[1]), max(E, 1), _ptr(common[0]), _ptr(common[1]),
+                                   _ptr(counts), _ptr(totals), _ptr(ws), ws.numel()))
+        res.append(DeviceViews(rows, masks, edges, common, counts, totals, vp))
+    if cjobs:
+        L.check(l.gmp_aug_two_views_batch((L.AugViewsJob * len(cjobs))(*cjobs), len(cjobs), nmax, emax, seed & (2 ** 64 - 1), _stream(jobs[0][0])),
+                "gmp_aug_two_views_batch")
+        torch.cuda.current_stream(jobs[0][0].device).synchronize()          # (the per-job scratch above dies with this frame)
+    return res

@@ -487,6 +487,32 @@ int gmp_aug_two_views(const int64_t* ptr, const int64_t* eptr, const int64_t* ed
                       uint64_t seed, uint32_t stream_id, int64_t* rows1, int64_t* rows2, uint64_t* rowmask1, uint64_t* rowmask2,
                       int64_t* edges1, int64_t* edges2, int64_t edge_capacity, int64_t* common1, int64_t* common2, int32_t* counts,
                       int32_t* totals_and_flags, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+/* The same for all the jobs of a step -- one per (task, domain) pair -- in one launch (masks) / two launches (views): host arrays of
+ * plain-data jobs whose fields are the arguments of the calls above (seed shared, stream_id per job); results identical to them. */
+typedef struct {
+    const int64_t *ptr, *out_ptr;
+    int32_t num_graphs;
+    uint32_t stream_id;
+    int64_t* out_idx;
+} gmp_aug_masks_job;
+typedef struct {
+    const int64_t *ptr, *eptr, *edge_index;
+    int64_t num_nodes, num_edges;
+    const int64_t* view_ptr;
+    int32_t num_graphs, num_features;
+    uint32_t stream_id;
+    int64_t *rows1, *rows2;
+    uint64_t *rowmask1, *rowmask2;
+    int64_t *edges1, *edges2;
+    int64_t edge_capacity;
+    int64_t *common1, *common2;
+    int32_t *counts, *totals_and_flags;
+    void* workspace;
+    size_t workspace_bytes;
+} gmp_aug_views_job;
+int gmp_aug_node_masks_batch(const gmp_aug_masks_job* jobs, int count, int64_t max_graph_nodes, uint64_t seed, gmp_stream_t stream);
+int gmp_aug_two_views_batch(const gmp_aug_views_job* jobs, int count, int64_t max_graph_nodes, int64_t max_graph_edges, uint64_t seed,
+                            gmp_stream_t stream);
 
 #ifdef __cplusplus
 }

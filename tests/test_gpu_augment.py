@@ -185,3 +185,29 @@ def test_device_draws_have_the_reference_distributions():
     keep_n = n - max(1, int(n * .2))
     assert np.abs(kept / T - keep_n / n).max() < 0.08                # sigma ~ 0.016 per node
     assert abs(coin_e / T - 0.2) < 0.06 and abs(coin_a / T - 0.2) < 0.06
+
+
+def test_batched_launches_equal_the_per_job_calls():
+    """gmp_aug_node_masks_batch / gmp_aug_two_views_batch (all the (task, domain) jobs of a step in one / two launches): bit-identical to
+    the per-job calls, with more jobs than one launch carries (8), a job without graphs, and graphs of 1 and 2 nodes."""
+    bs = _batches() + _batches()[:4]                                    # 11 jobs
+    empty = Batch.empty(4)
+    bs.insert(3, empty)
+    dev = lambda b: (torch.tensor(b.ptr_host, dtype=torch.long, device=DEV), torch.tensor(b.edge_ptr_host, dtype=torch.long, device=DEV),
+                     b.edge_index.to(DEV).contiguous())
+    on_dev = [dev(b) for b in bs]
+    masks = ops.aug_node_masks_batch([(d[0], b.ptr_host, 3 + 2 * i) for i, (b, d) in enumerate(zip(bs, on_dev))], 991)
+    views = ops.aug_two_views_batch([(d[0], d[1], d[2], b.ptr_host, b.edge_ptr_host, int(b.x.size(1)), 40 + 2 * i)
+                                     for i, (b, d) in enumerate(zip(bs, on_dev))], 991)
+    for i, (b, d) in enumerate(zip(bs, on_dev)):
+        assert torch.equal(masks[i], ops.aug_node_masks(d[0], b.ptr_host, 991, 3 + 2 * i))
+        if b.num_graphs == 0:
+            continue
+        one = ops.aug_two_views(d[0], d[1], d[2], b.ptr_host, b.edge_ptr_host, int(b.x.size(1)), 991, 40 + 2 * i)
+        got = views[i]
+        tot = one.totals.cpu().tolist()
+        assert got.totals.cpu().tolist() == tot and torch.equal(got.counts, one.counts)
+        for v in range(2):
+            assert torch.equal(got.rows[v], one.rows[v]) and torch.equal(got.rowmask[v], one.rowmask[v])
+            assert torch.equal(got.edges[v][:, :tot[v]], one.edges[v][:, :tot[v]])
+            assert torch.equal(got.common[v][:tot[2]], one.common[v][:tot[2]])
