@@ -27,6 +27,81 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float4* __r
     }
 }
 
+// ---- the 256 -> 1 layer of the link-prediction scorer (heads.py:45-52: Linear(hidden, 1) behind ReLU + dropout) without GEMM launches:
+// a [M, F] x [F] product is one dot product per row, its input gradient an outer product, its weight gradient a weighted column sum --
+// 12 + 11 + 54 us through the GEMM paths (N = 1 tiles, a [1 x F] grouped reduction), a few us as what they are: passes over [M, F].
+// y[m] = sum_c dropout(x)[m, c] * w[c] + b; d (nullable when p = 0) receives dropout(x).  One wave per row, lanes stride float4.
+__global__ __launch_bounds__(256) void dropout_rowdot_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ b,
+                                                             float4* __restrict__ d, float* __restrict__ y, int64_t M, int F4, float p,
+                                                             uint64_t seed, uint32_t sid) {
+    const int lane = threadIdx.x % 64;
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const float bias = b ? b[0] : 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + threadIdx.x / 64; m < M; m += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < F4; c += 64) {
+            const int64_t i = m * F4 + c;
+            float4 v = x[i];
+            if (p > 0.f) {
+                const float4 k = gmp::dropout_scale4(seed, sid, (uint64_t)i, p, inv);
+                v = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
+                d[i] = v;
+            }
+            const float4 ww = w[c];
+            s += (v.x * ww.x + v.y * ww.y) + (v.z * ww.z + v.w * ww.w);
+        }
+        s = gmp::wave_sum(s);
+        if (lane == 0) y[m] = s + bias;
+    }
+}
+
+// out[m, c] = g[m] * w[c] * dropmask * (act[m, c] > 0): the input gradient of that layer pushed through the dropout and the ReLU in front of it
+__global__ __launch_bounds__(256) void outer_relu_dropout_bwd_kernel(const float* __restrict__ g, const float4* __restrict__ w, const float4* __restrict__ act,
+                                                                     float4* __restrict__ out, int64_t n4, int F4, float p, uint64_t seed, uint32_t sid) {
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / F4;
+        const float gm = g[m];
+        const float4 ww = w[i - m * F4], a = act[i];
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) k = gmp::dropout_scale4(seed, sid, (uint64_t)i, p, inv);
+        out[i] = make_float4(a.x > 0.f ? gm * ww.x * k.x : 0.f, a.y > 0.f ? gm * ww.y * k.y : 0.f, a.z > 0.f ? gm * ww.z * k.z : 0.f,
+                             a.w > 0.f ? gm * ww.w * k.w : 0.f);
+    }
+}
+
+// weight / bias gradient of that layer: part[j][c] = sum over the j-th 256-row chunk of g[m] * X[m, c] (+ the chunk's sum of g in column F),
+// then the chunks in order: deterministic
+constexpr int WCS_ROWS = 256;
+__global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ X, float* __restrict__ part,
+                                                                      int64_t M, int F) {
+    __shared__ float sh[4][64];
+    __shared__ float shg[4];
+    const int c = threadIdx.x % 64, rl = threadIdx.x / 64;
+    const int64_t col = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * WCS_ROWS, r1 = r0 + WCS_ROWS < M ? r0 + WCS_ROWS : M;
+    float s = 0.f, sg = 0.f;
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const float gr = g[r];
+        if (col < F) s += gr * X[r * F + col];
+        sg += gr;
+    }
+    sh[rl][c] = s;
+    if (c == 0) shg[rl] = sg;
+    __syncthreads();
+    if (rl == 0 && col < F) part[(int64_t)blockIdx.y * (F + 1) + col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+    if (threadIdx.x == 0 && blockIdx.x == 0) part[(int64_t)blockIdx.y * (F + 1) + F] = (shg[0] + shg[1]) + (shg[2] + shg[3]);
+}
+__global__ __launch_bounds__(256) void weighted_colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out_w, float* __restrict__ out_b,
+                                                                    int64_t nparts, int F) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col > F) return;
+    float s = 0.f;
+    for (int64_t q = 0; q < nparts; ++q) s += part[q * (F + 1) + col];
+    if (col < F) out_w[col] = s;
+    else if (out_b) out_b[0] = s;
+}
+
 int grid_for(int64_t n4) {
     int64_t b = (n4 + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -52,4 +127,49 @@ extern "C" int gmp_relu_dropout_bwd(const float* g, const float* act, float* out
     hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)g, (const float4*)act, (float4*)out, numel / 4, p, seed, stream_id);
     return gmp::check_launch("relu_dropout_bwd_kernel");
+}
+
+extern "C" int gmp_dropout_rowdot_fwd(const float* x, const float* w, const float* bias, float* dropped, float* y, int64_t rows, int feat, float p,
+                                      uint64_t seed, uint32_t stream_id, gmp_stream_t stream) {
+    if (rows < 0 || feat <= 0 || feat % 4 || p < 0.f || p >= 1.f) return gmp::fail(GMP_ERR_ARG, "dropout_rowdot_fwd: rows=%lld feat=%d p=%f", (long long)rows, feat, p);
+    if (rows == 0) return GMP_OK;
+    if (!x || !w || !y || (p > 0.f && !dropped)) return gmp::fail(GMP_ERR_ARG, "dropout_rowdot_fwd: null pointer");
+    const int64_t blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(dropout_rowdot_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)w, bias, (float4*)dropped, y, rows, feat / 4, p, seed, stream_id);
+    return gmp::check_launch("dropout_rowdot_kernel");
+}
+
+extern "C" int gmp_outer_relu_dropout_bwd(const float* g, const float* w, const float* act, float* out, int64_t rows, int feat, float p,
+                                          uint64_t seed, uint32_t stream_id, gmp_stream_t stream) {
+    if (rows < 0 || feat <= 0 || feat % 4 || p < 0.f || p >= 1.f) return gmp::fail(GMP_ERR_ARG, "outer_relu_dropout_bwd: rows=%lld feat=%d p=%f", (long long)rows, feat, p);
+    if (rows == 0) return GMP_OK;
+    if (!g || !w || !act || !out) return gmp::fail(GMP_ERR_ARG, "outer_relu_dropout_bwd: null pointer");
+    const int64_t n4 = rows * (feat / 4);
+    hipLaunchKernelGGL(outer_relu_dropout_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, g, (const float4*)w, (const float4*)act,
+                       (float4*)out, n4, feat / 4, p, seed, stream_id);
+    return gmp::check_launch("outer_relu_dropout_bwd_kernel");
+}
+
+extern "C" size_t gmp_weighted_colsum_workspace_bytes(int64_t rows, int feat) {
+    if (rows <= 0 || feat <= 0) return 0;
+    return (size_t)((rows + WCS_ROWS - 1) / WCS_ROWS) * (size_t)(feat + 1) * sizeof(float);
+}
+
+extern "C" int gmp_weighted_colsum(const float* g, const float* x, float* out_w, float* out_b, int64_t rows, int feat, void* ws, size_t ws_bytes,
+                                   gmp_stream_t stream) {
+    if (rows < 0 || feat <= 0) return gmp::fail(GMP_ERR_ARG, "weighted_colsum: rows=%lld feat=%d", (long long)rows, feat);
+    if (!out_w) return gmp::fail(GMP_ERR_ARG, "weighted_colsum: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        (void)hipMemsetAsync(out_w, 0, (size_t)feat * sizeof(float), st);
+        if (out_b) (void)hipMemsetAsync(out_b, 0, sizeof(float), st);
+        return GMP_OK;
+    }
+    if (!g || !x) return gmp::fail(GMP_ERR_ARG, "weighted_colsum: null pointer");
+    if (!ws || ws_bytes < gmp_weighted_colsum_workspace_bytes(rows, feat)) return gmp::fail(GMP_ERR_WORKSPACE, "weighted_colsum: workspace");
+    const int64_t parts = (rows + WCS_ROWS - 1) / WCS_ROWS;
+    hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3((unsigned)((feat + 63) / 64), (unsigned)parts), dim3(256), 0, st, g, x, (float*)ws, rows, feat);
+    hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((unsigned)((feat + 1 + 255) / 256)), dim3(256), 0, st, (const float*)ws, out_w, out_b, parts, feat);
+    return gmp::check_launch("weighted_colsum kernels");
 }

@@ -174,14 +174,14 @@ int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1
             const float *w0 = d.flat + t.lp_off_w0, *b0 = d.flat + t.lp_off_b0, *w3 = d.flat + t.lp_off_w3, *b3 = d.flat + t.lp_off_b3;
             GMP_TRY(gmp_lp_edge_features_fwd(hL, t.lp_edges, t.lp_feat, N, K, H, st));
             GMP_TRY(gemm(GMP_GEMM_NT, t.lp_feat, w0, b0, t.lp_y1, K, H, 3 * H, 3 * H, 3 * H, H, true, st));
-            int rc;
-            float* ld1 = drop(d, t.lp_y1, t.lp_d1, K * H, t.lp_site, st, &rc);
-            GMP_TRY(rc);
-            GMP_TRY(gemm(GMP_GEMM_NT, ld1, w3, b3, t.lp_y2, K, 1, H, H, H, 1, false, st));
+            // the 256 -> 1 layer: a dot product per row with the dropout in the same pass, and its input gradient as an outer product
+            // pushed through the dropout and the ReLU (gmp_dropout_rowdot_fwd / gmp_outer_relu_dropout_bwd: no N = 1 GEMM launches)
+            const float pdrop = d.training && d.dropout_p > 0.f ? d.dropout_p : 0.f;
+            float* ld1 = pdrop > 0.f ? t.lp_d1 : t.lp_y1;
+            GMP_TRY(gmp_dropout_rowdot_fwd(t.lp_y1, w3, b3, t.lp_d1, t.lp_y2, K, H, pdrop, d.seed, t.lp_site, st));
             GMP_TRY(gmp_sigmoid_bce_signed_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
             *d1_out = ld1;
-            GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy2, w3, nullptr, t.lp_gy1, K, H, 1, 1, H, H, false, st));
-            GMP_TRY(gmp_relu_dropout_bwd(t.lp_gy1, t.lp_y1, t.lp_gy1, K * H, d.training ? d.dropout_p : 0.f, d.seed, t.lp_site, st));
+            GMP_TRY(gmp_outer_relu_dropout_bwd(t.lp_gy2, w3, t.lp_y1, t.lp_gy1, K, H, pdrop, d.seed, t.lp_site, st));
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy1, w0, nullptr, t.lp_gfeat, K, 3 * H, H, H, 3 * H, 3 * H, false, st));
             GMP_TRY(gmp_lp_edge_features_bwd(t.lp_gfeat, hL, t.lp_edges, t.lp_ghs, t.lp_ghd, N, K, H, st));
             float* g_rows = gH + (int64_t)H * t.row0;
@@ -277,12 +277,12 @@ int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1)
         case GMP_TASK_LP: {
             const int64_t K = t.lp_K;
             const int32_t one[2] = {0, (int32_t)K};
-            const int64_t cw3[1] = {t.lp_tg_w3}, cb3[1] = {t.lp_tg_b3}, cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
-            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy2, d1, nullptr, tg, 1, one, nullptr, nullptr, cw3, tg, cb3, 1, H, 0, 1, H, H, 1.f, 0, 0,
-                                         t.gemm_ws, t.gemm_ws_bytes, st));
-            // dW0 with db0 riding along (column sums of the A tile already in LDS)
-            return gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
-                                        1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st);
+            const int64_t cw0[1] = {t.lp_tg_w0}, cb0[1] = {t.lp_tg_b0};
+            // dW0 with db0 riding along (column sums of the A tile already in LDS); first: this GEMM carries the "input half done" signal
+            GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
+                                         1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
+            // dW3 [1, 256] and db3: a weighted column sum (the grouped GEMM path took 54 us for these 257 numbers)
+            return gmp_weighted_colsum(t.lp_gy2, d1, tg + t.lp_tg_w3, tg + t.lp_tg_b3, K, H, t.gemm_ws, t.gemm_ws_bytes, st);
         }
         case GMP_TASK_DA: {
             const int B = t.pool_B, Hd = t.da_hidden, Cc = t.da_classes;

@@ -1311,18 +1311,23 @@ class StepEngine:
             w3, b3 = P("heads.link_pred.predictor.mlp.3.weight"), P("heads.link_pred.predictor.mlp.3.bias")
             self._chk(lib.gmp_lp_edge_features_fwd(hL.data_ptr(), p.d64["lp_edges"], hd["lp_feat"].data_ptr(), N, K, H, st), "lp feat")
             self._gemm(NT, hd["lp_feat"].data_ptr(), w0, b0, hd["lp_y1"].data_ptr(), K, H, 3 * H, 3 * H, 3 * H, H, relu=True)
-            d1 = self._drop(hd["lp_y1"], hd["lp_d1"], K * H, 100 + ti)
-            self._gemm(NT, d1.data_ptr(), w3, b3, self.lp_y2.data_ptr(), K, 1, H, H, H, 1)
+            # the 256 -> 1 layer as a row dot product / outer product / weighted column sum (csrc/elementwise.hip), as in csrc/step.hip
+            pdrop = self.dropout_p if (self.model.training and self.dropout_p > 0) else 0.0
+            dseed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
+            d1 = hd["lp_d1"] if pdrop > 0 else hd["lp_y1"]
+            self._chk(lib.gmp_dropout_rowdot_fwd(hd["lp_y1"].data_ptr(), w3, b3, hd["lp_d1"].data_ptr(), self.lp_y2.data_ptr(), K, H, pdrop, dseed,
+                                                 100 + ti, st), "lp rowdot")
             self._chk(lib.gmp_sigmoid_bce_signed_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
                                                       self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "sigmoid+bce")
             one = [0, K]
-            self._gemm_g(TN, self.lp_gy2.data_ptr(), d1.data_ptr(), None, tg, one, None, None, [TG(ti, "heads.link_pred.predictor.mlp.3.weight")],
-                         tg, [TG(ti, "heads.link_pred.predictor.mlp.3.bias")], 1, H, 0, 1, H, H)
-            self._gemm(NN, self.lp_gy2.data_ptr(), w3, None, hd["lp_gy1"].data_ptr(), K, H, 1, 1, H, H)
-            self._relu_drop_bwd(hd["lp_gy1"], hd["lp_y1"], hd["lp_gy1"], K * H, 100 + ti)
+            self._chk(lib.gmp_outer_relu_dropout_bwd(self.lp_gy2.data_ptr(), w3, hd["lp_y1"].data_ptr(), hd["lp_gy1"].data_ptr(), K, H, pdrop, dseed,
+                                                     100 + ti, st), "lp outer")
             # dW0 with db0 riding along (column sums of the A tile already in LDS)
             self._gemm_g(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg, one, None, None,
                          [TG(ti, "heads.link_pred.predictor.mlp.0.weight")], tg, [TG(ti, "heads.link_pred.predictor.mlp.0.bias")], H, 3 * H, 0, H, 3 * H, 3 * H)
+            self._chk(lib.gmp_weighted_colsum(self.lp_gy2.data_ptr(), d1.data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.weight"),
+                                              tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.bias"), K, H, self._cur_gemm_ws.data_ptr(),
+                                              self._cur_gemm_ws.numel(), st), "lp dW3")
             self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
             self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
                                                    hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")

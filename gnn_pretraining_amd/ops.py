@@ -607,3 +607,34 @@ def aug_two_views_batch(jobs, seed: int):
                 "gmp_aug_two_views_batch")
         torch.cuda.current_stream(jobs[0][0].device).synchronize()          # (the per-job scratch above dies with this frame)
     return res
+
+
+def dropout_rowdot_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], p: float, seed: int, stream_id: int):
+    """(dropout(x), dropout(x) @ w + bias) for a Linear(F, 1) (gmp_dropout_rowdot_fwd); the dropped copy is x itself when p == 0."""
+    _need(x, torch.float32, "x", 2)
+    rows, F = x.shape
+    d = torch.empty_like(x) if p > 0 else x
+    y = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().gmp_dropout_rowdot_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(d), _ptr(y), rows, F, float(p), seed & (2 ** 64 - 1), stream_id,
+                                           _stream(x)), "gmp_dropout_rowdot_fwd")
+    return d, y
+
+
+def outer_relu_dropout_bwd(g: Tensor, w: Tensor, act: Tensor, p: float, seed: int, stream_id: int) -> Tensor:
+    """g[m] * w[c] pushed through the dropout mask of the forward and the ReLU whose output was `act` (gmp_outer_relu_dropout_bwd)."""
+    rows, F = act.shape
+    out = torch.empty_like(act)
+    L.check(L.lib().gmp_outer_relu_dropout_bwd(_ptr(g), _ptr(w), _ptr(act), _ptr(out), rows, F, float(p), seed & (2 ** 64 - 1), stream_id,
+                                               _stream(act)), "gmp_outer_relu_dropout_bwd")
+    return out
+
+
+def weighted_colsum(g: Tensor, x: Tensor):
+    """(sum_m g[m] x[m, :], sum_m g[m]) -- weight and bias gradient of a Linear(F, 1) (gmp_weighted_colsum)."""
+    rows, F = x.shape
+    ow = torch.empty(F, dtype=torch.float32, device=x.device)
+    ob = torch.empty(1, dtype=torch.float32, device=x.device)
+    l = L.lib()
+    ws = _ws(l.gmp_weighted_colsum_workspace_bytes(rows, F), x.device)
+    L.check(l.gmp_weighted_colsum(_ptr(g), _ptr(x), _ptr(ow), _ptr(ob), rows, F, _ptr(ws), ws.numel(), _stream(x)), "gmp_weighted_colsum")
+    return ow, ob

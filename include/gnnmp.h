@@ -290,6 +290,18 @@ int gmp_dropout_fwd(const float* x, float* y, int64_t numel, float p, uint64_t s
                     gmp_stream_t stream);
 int gmp_relu_dropout_bwd(const float* g, const float* act, float* out, int64_t numel, float p, uint64_t seed,
                          uint32_t stream_id, gmp_stream_t stream);
+/* The Linear(hidden, 1) that ends the link-prediction scorer (src/models/heads.py:45-52, behind ReLU + dropout) as what it is -- a dot
+ * product per row, an outer product, a weighted column sum -- instead of three GEMM-path launches with N = 1:
+ *   gmp_dropout_rowdot_fwd:      dropped = dropout(x) (written when p > 0; may be NULL otherwise), y[m] = <dropped[m, :], w> + bias[0]
+ *   gmp_outer_relu_dropout_bwd:  out[m, c] = g[m] * w[c] * dropout_mask * (act[m, c] > 0)   (same site / seed as the forward)
+ *   gmp_weighted_colsum:         out_w[c] = sum_m g[m] * x[m, c], out_b[0] = sum_m g[m] (nullable); two ordered stages, deterministic */
+int gmp_dropout_rowdot_fwd(const float* x, const float* w, const float* bias, float* dropped, float* y, int64_t rows, int feat, float p,
+                           uint64_t seed, uint32_t stream_id, gmp_stream_t stream);
+int gmp_outer_relu_dropout_bwd(const float* g, const float* w, const float* act, float* out, int64_t rows, int feat, float p,
+                               uint64_t seed, uint32_t stream_id, gmp_stream_t stream);
+size_t gmp_weighted_colsum_workspace_bytes(int64_t rows, int feat);
+int gmp_weighted_colsum(const float* g, const float* x, float* out_w, float* out_b, int64_t rows, int feat, void* workspace,
+                        size_t workspace_bytes, gmp_stream_t stream);
 
 /* Grouped form: the per-domain problems of one contrastive task (tasks.py:192-213, 265-287 loop over domains) in 7 launches
  * instead of 7 per domain; forward and backward in one call.  Group g's 2*n_host[g] rows [z1; z2] start at row

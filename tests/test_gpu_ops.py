@@ -511,3 +511,33 @@ def test_csr_build_segmented_equals_the_whole_batch_build():
     assert int(status) == 1
     with pytest.raises(Exception):
         L.check(l.gmp_csr_build_segmented(ops._ptr(ei), N, E, ops._ptr(sr), ops._ptr(se), Sg, 100000, me, *[ops._ptr(t) for t in out], ops._ptr(status), st), "seg")
+
+
+@pytest.mark.parametrize("rows", [0, 1, 255, 15431])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_linear_to_one_column_kernels(rows, p):
+    """The scorer's Linear(hidden, 1) behind ReLU + dropout (src/models/heads.py:45-52) as row dot / outer product / weighted column
+    sum: against torch in fp64 with the mask the library's own dropout kernel draws for the same (seed, site) -- 1e-5 of the largest
+    entry (fp32 sums over 256 columns / 15 k rows); the dropped copy and the mask are bit-identical to gmp_dropout_fwd's."""
+    gen = torch.Generator().manual_seed(rows + 7)
+    F = 256
+    x = torch.relu(torch.randn(rows, F, generator=gen)).to(DEV)
+    w, b = torch.randn(F, generator=gen).to(DEV), torch.randn(1, generator=gen).to(DEV)
+    g = torch.randn(rows, generator=gen).to(DEV)
+    d, y = ops.dropout_rowdot_fwd(x, w, b, p, 99, 103)
+    d_ref = ops.dropout_fwd(x, p, 99, 103) if p > 0 else x
+    assert torch.equal(d, d_ref)
+    if rows == 0:
+        ow, ob = ops.weighted_colsum(g, d)
+        assert ow.abs().max().item() == 0 and ob.item() == 0
+        return
+    y_ref = d_ref.double() @ w.double() + b.double()
+    assert (y.double() - y_ref).abs().max().item() <= 1e-5 * max(y_ref.abs().max().item(), 1.0)
+    gi = ops.outer_relu_dropout_bwd(g, w, x, p, 99, 103)
+    keep = (d_ref != 0).double() / (1 - p) if p > 0 else (x > 0).double()
+    gi_ref = g.double()[:, None] * w.double()[None, :] * keep
+    assert (gi.double() - gi_ref).abs().max().item() <= 1e-6 * max(gi_ref.abs().max().item(), 1.0)
+    ow, ob = ops.weighted_colsum(g, d)
+    ow_ref, ob_ref = g.double() @ d_ref.double(), g.double().sum()
+    assert (ow.double() - ow_ref).abs().max().item() <= 1e-5 * max(ow_ref.abs().max().item(), 1.0)
+    assert abs(ob.item() - ob_ref.item()) <= 1e-5 * max(abs(ob_ref.item()), g.abs().sum().item() * 1e-2, 1.0)
