@@ -396,7 +396,9 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (ts != main && ts != aux) { fwd_b = ts; break; }
     }
     const size_t bn_fwd_slice = gmp_bn_workspace_bytes(N, 2 * H, d.S, d.max_seg);
-    const bool split_fwd = d.fwd_split_seg > 0 && d.fwd_split_seg < d.S && d.fwd_split_row > 0 && d.fwd_split_row < N && fwd_b != main &&
+    // (both ranges at least 1,024 rows: below that gmp_gemm_f32 runs its first kernel, whose K order differs from the pipelined one the
+    // single pass uses -- the split must not change a bit -- and a step that small has nothing to hide behind anyway)
+    const bool split_fwd = d.fwd_split_seg > 0 && d.fwd_split_seg < d.S && d.fwd_split_row >= 1024 && N - d.fwd_split_row >= 1024 && fwd_b != main &&
                            d.bn_ws_bytes >= 2 * bn_fwd_slice && N < 65536;
     struct Range { int s0, s1; int64_t r0, r1; hipStream_t st; void* ws; };
     Range ranges[2] = {{0, split_fwd ? d.fwd_split_seg : d.S, 0, split_fwd ? d.fwd_split_row : N, main, d.bn_ws},
