@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <string>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -363,6 +365,7 @@ pybind11::list draw_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
                 const at::Tensor &ptr = std::get<0>(doms[di]), &eptr = std::get<1>(doms[di]), &ei = std::get<2>(doms[di]);
                 const int64_t B = ptr.numel() - 1;
                 auto& r = res[t * D + di];
+                if (kinds[t] == 3 && B < 2) { none[t * D + di] = 1; continue; }      // no graph-contrast pair without two graphs (also: no graph at all)
                 if (B <= 0) continue;
                 switch (kinds[t]) {
                     case 0: r.push_back(mask_indices_core(ptr, impl)); break;
@@ -395,63 +398,70 @@ pybind11::list draw_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
 // collation and batched_negative_sampling both are); ptr: the batch's node offsets.  Returns pairs [2, K'] (min, max) + offset --
 // all positives, then all negatives, each in first-occurrence order -- and signed multiplicities (+count positives, -count
 // negatives).  Pairs never cross graphs, so the counting table is one graph's n x n (a few KB: it stays in L1).
+// shared by merge_mirrored_pairs and plan_step: appends the merged pairs of ONE domain batch to (oa, ob, ow); returns an error text or null
+static const char* merge_pairs_core(const int64_t* ps, const int64_t* pd, int64_t Ep, const int64_t* ns, const int64_t* nd, int64_t En,
+                                    const int64_t* p, int64_t G, int64_t offset, std::vector<int64_t>& oa, std::vector<int64_t>& ob,
+                                    std::vector<float>& ow, std::vector<uint16_t>& count) {
+    size_t out = oa.size();
+    oa.resize(out + (size_t)(Ep + En)); ob.resize(out + (size_t)(Ep + En)); ow.resize(out + (size_t)(Ep + En));
+    int64_t *wa = oa.data(), *wb = ob.data();
+    float* ww = ow.data();
+    const char* err = nullptr;
+    for (int grp = 0; grp < 2 && !err; ++grp) {
+        const int64_t E = grp ? En : Ep;
+        const int64_t *s = grp ? ns : ps, *d = grp ? nd : pd;
+        const float sign = grp ? -1.f : 1.f;
+        int64_t e = 0;
+        for (int64_t gi = 0; gi < G && e < E && !err; ++gi) {
+            const int64_t lo = p[gi], hi = p[gi + 1], n = hi - lo;
+            int64_t e1 = e;
+            while (e1 < E && s[e1] >= lo && s[e1] < hi) ++e1;             // this graph's run of pairs
+            if (e1 == e) continue;
+            if (n > 4096) { err = "hostdraw: graph too large for the pair table"; break; }
+            if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);      // (every touched entry is reset below: all zero between graphs)
+            for (int64_t k = e; k < e1; ++k) {
+                const int64_t x = s[k] - lo, y = d[k] - lo;
+                if (y < 0 || y >= n) { err = "hostdraw: pair crosses graphs"; break; }
+                uint16_t& c = count[(size_t)((x < y ? x : y) * n + (x < y ? y : x))];
+                if (c == 65535) { err = "hostdraw: pair multiplicity overflow"; break; }
+                ++c;
+            }
+            if (err) break;
+            for (int64_t k = e; k < e1; ++k) {
+                const int64_t x = s[k] - lo, y = d[k] - lo, a = x < y ? x : y, b = x < y ? y : x;
+                uint16_t& c = count[(size_t)(a * n + b)];
+                // branch-free: half of these tests go either way with no pattern (fresh pairs every step), a mispredict each
+                wa[out] = a + lo + offset; wb[out] = b + lo + offset; ww[out] = sign * (float)c;
+                out += c != 0;
+                c = 0;
+            }
+            e = e1;
+        }
+        if (!err && e != E) err = "hostdraw: pairs are not grouped by graph in batch order";
+    }
+    if (err) std::fill(count.begin(), count.end(), 0);            // (a failed call may have left counts behind)
+    oa.resize(out); ob.resize(out); ow.resize(out);
+    return err;
+}
+
 std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at::Tensor ptr, int64_t offset) {
     for (const at::Tensor* t : {&pos, &neg})
         TORCH_CHECK(t->dim() == 2 && t->size(0) == 2 && t->scalar_type() == at::kLong && t->is_contiguous() && t->device().is_cpu(),
                     "hostdraw: pairs must be contiguous CPU int64 [2, E]");
     TORCH_CHECK(ptr.dim() == 1 && ptr.numel() >= 1 && ptr.scalar_type() == at::kLong && ptr.is_contiguous(), "hostdraw: ptr");
-    const int64_t cap = pos.size(1) + neg.size(1);
     static thread_local std::vector<int64_t> va, vb;          // scratch that keeps its capacity across calls
     static thread_local std::vector<float> vw;
     static thread_local std::vector<uint16_t> count;
-    va.resize((size_t)cap); vb.resize((size_t)cap); vw.resize((size_t)cap);
-    int64_t out = 0;
-    const char* err = nullptr;
+    va.clear(); vb.clear(); vw.clear();
+    const char* err;
     {
         pybind11::gil_scoped_release nogil;
-        int64_t *oa = va.data(), *ob = vb.data();
-        float* ow = vw.data();
-        const int64_t* p = ptr.data_ptr<int64_t>();
-        const int64_t G = ptr.numel() - 1;
-        for (int grp = 0; grp < 2 && !err; ++grp) {
-            const at::Tensor& t = grp ? neg : pos;
-            const int64_t E = t.size(1);
-            const int64_t *s = t.data_ptr<int64_t>(), *d = s + E;
-            const float sign = grp ? -1.f : 1.f;
-            int64_t e = 0;
-            for (int64_t gi = 0; gi < G && e < E && !err; ++gi) {
-                const int64_t lo = p[gi], hi = p[gi + 1], n = hi - lo;
-                int64_t e1 = e;
-                while (e1 < E && s[e1] >= lo && s[e1] < hi) ++e1;             // this graph's run of pairs
-                if (e1 == e) continue;
-                if (n > 4096) { err = "hostdraw: graph too large for the pair table"; break; }
-                if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);      // (every touched entry is reset below: all zero between graphs)
-                for (int64_t k = e; k < e1; ++k) {
-                    const int64_t x = s[k] - lo, y = d[k] - lo;
-                    if (y < 0 || y >= n) { err = "hostdraw: pair crosses graphs"; break; }
-                    uint16_t& c = count[(size_t)((x < y ? x : y) * n + (x < y ? y : x))];
-                    if (c == 65535) { err = "hostdraw: pair multiplicity overflow"; break; }
-                    ++c;
-                }
-                if (err) break;
-                for (int64_t k = e; k < e1; ++k) {
-                    const int64_t x = s[k] - lo, y = d[k] - lo, a = x < y ? x : y, b = x < y ? y : x;
-                    uint16_t& c = count[(size_t)(a * n + b)];
-                    if (c) {
-                        oa[out] = a + lo + offset; ob[out] = b + lo + offset; ow[out] = sign * (float)c;
-                        ++out;
-                        c = 0;
-                    }
-                }
-                e = e1;
-            }
-            if (!err && e != E) err = "hostdraw: pairs are not grouped by graph in batch order";
-        }
+        const int64_t Ep = pos.size(1), En = neg.size(1);
+        err = merge_pairs_core(pos.data_ptr<int64_t>(), pos.data_ptr<int64_t>() + Ep, Ep, neg.data_ptr<int64_t>(), neg.data_ptr<int64_t>() + En, En,
+                               ptr.data_ptr<int64_t>(), ptr.numel() - 1, offset, va, vb, vw, count);
     }
-    if (err) {
-        std::fill(count.begin(), count.end(), 0);              // (a failed call may have left counts behind)
-        TORCH_CHECK(false, err);
-    }
+    TORCH_CHECK(!err, err);
+    const int64_t out = (int64_t)va.size();
     at::Tensor pairs = at::empty({2, out}, at::kLong), w = at::empty({out}, at::kFloat);
     if (out) {
         std::memcpy(pairs.data_ptr<int64_t>(), va.data(), (size_t)out * sizeof(int64_t));
@@ -459,6 +469,301 @@ std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at:
         std::memcpy(w.data_ptr<float>(), vw.data(), (size_t)out * sizeof(float));
     }
     return {pairs, w};
+}
+
+// engine.StepEngine.plan in one call with the GIL released: the stacked layout of a step -- segments (one per reference forward()
+// call), the per-task index arrays, the link-prediction pair list with mirrored pairs merged, the tiles, and the two upload images
+// (int32 / int64, every array 16-byte aligned) -- from the raw result of draw_step.  Array for array what the Python plan builds
+// (tests/test_hostdraw.py compares them); the Python version stays for the other index modes and as the reading copy.
+// kinds: engine task order (0 node_feat_mask, 1 link_pred, 2 node_contrast, 3 graph_contrast, 4 graph_prop, 5 domain_adv);
+// art[t][d] for kinds 0..3 in the same order: the tuples draw_step returns (None where the reference skips the pair).
+namespace {
+struct Img {                                   // one named array of an upload image
+    std::string name;
+    std::vector<int64_t> v;
+};
+struct PlanOut {
+    std::vector<Img> a32, a64;
+    std::vector<int64_t>& add(std::vector<Img>& img, const char* name) {
+        img.push_back(Img{name, {}});
+        return img.back().v;
+    }
+};
+}  // namespace
+
+pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, int64_t>> doms,
+                         std::vector<int64_t> row_off, pybind11::list art, bool lp_merge, bool want_split, int64_t hidden, int64_t prop_dim) {
+    const size_t T = kinds.size(), D = doms.size();
+    TORCH_CHECK(row_off.size() == D, "plan_step: one row offset per domain");
+    // ---- unpack the artefacts while the GIL is held (tensor handles only)
+    struct Art { bool none = false; std::vector<at::Tensor> t; };
+    std::vector<std::vector<Art>> arts(T, std::vector<Art>(D));
+    {
+        size_t ai = 0;
+        for (size_t t = 0; t < T; ++t) {
+            if (kinds[t] > 3) continue;
+            TORCH_CHECK(ai < (size_t)pybind11::len(art), "plan_step: artefact list too short");
+            pybind11::list row = art[ai++].cast<pybind11::list>();
+            TORCH_CHECK((size_t)pybind11::len(row) == D, "plan_step: one artefact per domain");
+            for (size_t d = 0; d < D; ++d) {
+                pybind11::object o = row[d];
+                if (o.is_none()) { arts[t][d].none = true; continue; }
+                for (auto h : o.cast<pybind11::tuple>()) {
+                    at::Tensor x = h.cast<at::Tensor>();
+                    TORCH_CHECK(x.scalar_type() == at::kLong && x.is_contiguous() && x.device().is_cpu(), "plan_step: artefacts are contiguous CPU int64 tensors");
+                    arts[t][d].t.push_back(x);
+                }
+            }
+        }
+    }
+    for (auto& dm : doms) check_ptrs(std::get<0>(dm), std::get<1>(dm), std::get<2>(dm));
+
+    PlanOut out;
+    std::vector<int64_t> seg_ptr{0}, seg_dom, seg_task, task_row{0}, src_rows, e_src, e_dst, seg_edges;
+    std::vector<std::pair<int64_t, const int64_t*>> rowmask_at;       // (first row, per-row masks) of the views that drew one
+    std::vector<int64_t> rowmask_len;
+    std::vector<std::pair<int64_t, int64_t>> skipped;                 // (task, domain)
+    std::vector<float> lp_labels;
+    std::map<std::string, int64_t> sc;                                // scalars
+    std::map<std::string, std::vector<int64_t>> lists;
+    std::vector<int64_t> sizes(T, 0);
+    const char* err = nullptr;
+    {
+        pybind11::gil_scoped_release nogil;
+        {
+            int64_t nn = 0, ee = 0;
+            for (auto& dm : doms) { nn += std::get<0>(dm).data_ptr<int64_t>()[std::get<0>(dm).numel() - 1]; ee += std::get<2>(dm).size(1); }
+            src_rows.reserve((size_t)(nn * (T + 2))); e_src.reserve((size_t)(ee * (T + 2))); e_dst.reserve((size_t)(ee * (T + 2)));
+        }
+        auto n_of = [&](size_t d) { const at::Tensor& p = std::get<0>(doms[d]); return p.data_ptr<int64_t>()[p.numel() - 1]; };
+        auto add_segment = [&](int64_t ti, int64_t di, const int64_t* rows, int64_t nrows, int64_t roff, const int64_t* es, const int64_t* ed, int64_t ne) {
+            const int64_t r0 = seg_ptr.back();
+            {   // bulk appends (resize + a plain loop the compiler vectorises; element-wise push_back made this call as slow as numpy)
+                const size_t o = src_rows.size();
+                src_rows.resize(o + (size_t)nrows);
+                int64_t* w = src_rows.data() + o;
+                if (rows) for (int64_t i = 0; i < nrows; ++i) w[i] = rows[i] + roff;
+                else for (int64_t i = 0; i < nrows; ++i) w[i] = roff + i;
+                const size_t oe = e_src.size();
+                e_src.resize(oe + (size_t)ne); e_dst.resize(oe + (size_t)ne);
+                int64_t *ws = e_src.data() + oe, *wd = e_dst.data() + oe;
+                for (int64_t e = 0; e < ne; ++e) ws[e] = es[e] + r0;
+                for (int64_t e = 0; e < ne; ++e) wd[e] = ed[e] + r0;
+            }
+            seg_edges.push_back(ne);
+            seg_ptr.push_back(r0 + nrows); seg_dom.push_back(di); seg_task.push_back(ti);
+            return r0;
+        };
+        std::vector<int64_t> r0s;
+        for (size_t t = 0; t < T && !err; ++t) {
+            const int kind = kinds[t];
+            if (kind == 0 || kind == 1 || kind == 4 || kind == 5) {
+                r0s.clear();
+                for (size_t d = 0; d < D; ++d) {
+                    const at::Tensor& ei = std::get<2>(doms[d]);
+                    const int64_t E = ei.size(1);
+                    r0s.push_back(add_segment((int64_t)t, (int64_t)d, nullptr, n_of(d), row_off[d], ei.data_ptr<int64_t>(), ei.data_ptr<int64_t>() + E, E));
+                }
+                if (kind == 0) {
+                    auto& idx = out.add(out.a64, "nfm_idx");
+                    auto& rows = lists["nfm_rows"];
+                    rows.push_back(0);
+                    for (size_t d = 0; d < D; ++d) {
+                        int64_t m = 0;
+                        if (!arts[t][d].t.empty()) {
+                            const at::Tensor& x = arts[t][d].t[0];
+                            m = x.numel();
+                            for (int64_t i = 0; i < m; ++i) idx.push_back(x.data_ptr<int64_t>()[i] + r0s[d]);
+                        }
+                        if (m == 0) skipped.emplace_back((int64_t)t, (int64_t)d);
+                        rows.push_back(rows.back() + m);
+                    }
+                    sizes[t] = rows.back() * hidden;
+                } else if (kind == 1) {
+                    std::vector<int64_t> pa, pb, seg_eptr{0};
+                    int64_t ordered = 0;
+                    for (size_t d = 0; d < D && !err; ++d) {
+                        const at::Tensor& ptr = std::get<0>(doms[d]);
+                        const at::Tensor& ei = std::get<2>(doms[d]);
+                        const int64_t Ep = ei.size(1);
+                        const int64_t *ps = ei.data_ptr<int64_t>(), *pd = ps + Ep;
+                        const int64_t *ns = nullptr, *nd = nullptr;
+                        int64_t En = 0;
+                        if (!arts[t][d].t.empty()) {
+                            const at::Tensor& x = arts[t][d].t[0];
+                            if (x.dim() != 2 || x.size(0) != 2) { err = "plan_step: negatives must be [2, K]"; break; }
+                            En = x.size(1); ns = x.data_ptr<int64_t>(); nd = ns + En;
+                        }
+                        ordered += Ep + En;
+                        const int64_t before = (int64_t)pa.size();
+                        if (!lp_merge) {
+                            for (int64_t e = 0; e < Ep; ++e) { pa.push_back(ps[e] + r0s[d]); pb.push_back(pd[e] + r0s[d]); lp_labels.push_back(1.f); }
+                            for (int64_t e = 0; e < En; ++e) { pa.push_back(ns[e] + r0s[d]); pb.push_back(nd[e] + r0s[d]); lp_labels.push_back(-1.f); }
+                        } else {
+                            static thread_local std::vector<uint16_t> count;
+                            err = merge_pairs_core(ps, pd, Ep, ns, nd, En, ptr.data_ptr<int64_t>(), ptr.numel() - 1, r0s[d], pa, pb, lp_labels, count);
+                            if (err) break;
+                        }
+                        seg_eptr.push_back(seg_eptr.back() + (int64_t)pa.size() - before);
+                    }
+                    if (err) break;
+                    auto& le = out.add(out.a64, "lp_edges");
+                    le = pa; le.insert(le.end(), pb.begin(), pb.end());
+                    sc["lp_K"] = (int64_t)pa.size();
+                    sizes[t] = ordered;
+                    auto& lsp = out.add(out.a32, "lp_seg_ptr");
+                    lsp = r0s; lsp.push_back(seg_ptr.back());
+                    out.add(out.a32, "lp_seg_eptr") = seg_eptr;
+                    sc["lp_S"] = (int64_t)D; sc["lp_rows_end"] = seg_ptr.back();
+                    int64_t mr = 0, me = 0;
+                    for (size_t d = 0; d < D; ++d) { mr = std::max(mr, lsp[d + 1] - lsp[d]); me = std::max(me, seg_eptr[d + 1] - seg_eptr[d]); }
+                    sc["lp_max_rows"] = mr; sc["lp_max_edges"] = me;
+                } else {
+                    std::vector<int64_t> starts, rows{0}, labels;
+                    for (size_t d = 0; d < D; ++d) {
+                        const at::Tensor& ptr = std::get<0>(doms[d]);
+                        const int64_t* p = ptr.data_ptr<int64_t>();
+                        const int64_t B = ptr.numel() - 1;
+                        for (int64_t g = 0; g < B; ++g) { starts.push_back(r0s[d] + p[g]); labels.push_back((int64_t)d); }
+                        rows.push_back(rows.back() + B);
+                    }
+                    const int64_t end = seg_ptr.back(), B = (int64_t)starts.size();
+                    auto& pv = out.add(out.a32, kind == 4 ? "gp_ptr" : "da_ptr");
+                    pv = starts; pv.push_back(end);
+                    auto& gid = out.add(out.a64, kind == 4 ? "gp_gid" : "da_gid");
+                    gid.resize((size_t)(pv[B] - pv[0]));
+                    for (int64_t g = 0; g < B; ++g) std::fill(gid.begin() + (pv[g] - pv[0]), gid.begin() + (pv[g + 1] - pv[0]), g);
+                    if (kind == 4) {
+                        lists["gp_rows"] = rows; sc["gp_B"] = B; sc["gp_r0"] = task_row.back(); sc["gp_M"] = end - task_row.back();
+                        sizes[t] = rows.back() * prop_dim;
+                    } else {
+                        out.add(out.a64, "da_labels") = labels;
+                        sc["da_B"] = B; sc["da_r0"] = task_row.back(); sc["da_M"] = end - task_row.back();
+                        sizes[t] = B;
+                    }
+                }
+            } else {
+                std::vector<int64_t> idx, rows{0}, ns, starts;
+                for (size_t d = 0; d < D; ++d) {
+                    const Art& a = arts[t][d];
+                    if (a.none) { ns.push_back(0); rows.push_back(rows.back()); skipped.emplace_back((int64_t)t, (int64_t)d); continue; }
+                    int64_t r0v[2];
+                    for (int v = 0; v < 2; ++v) {
+                        if (a.t.empty()) { r0v[v] = add_segment((int64_t)t, (int64_t)d, nullptr, 0, row_off[d], nullptr, nullptr, 0); continue; }
+                        const at::Tensor &vr = a.t[5 * v], &ve = a.t[5 * v + 1], &vm = a.t[5 * v + 3];
+                        const int64_t ne = ve.size(1);
+                        r0v[v] = add_segment((int64_t)t, (int64_t)d, vr.data_ptr<int64_t>(), vr.numel(), row_off[d], ve.data_ptr<int64_t>(), ve.data_ptr<int64_t>() + ne, ne);
+                        if (vm.numel()) { rowmask_at.emplace_back(r0v[v], vm.data_ptr<int64_t>()); rowmask_len.push_back(vm.numel()); }
+                    }
+                    if (kind == 2) {
+                        int64_t n = 0;
+                        if (!a.t.empty()) {
+                            const at::Tensor &c1 = a.t[4], &c2 = a.t[9];
+                            n = (c1.numel() >= 2 && c2.numel() >= 2) ? c1.numel() : 0;
+                            if (n) {
+                                for (int64_t i = 0; i < c1.numel(); ++i) idx.push_back(c1.data_ptr<int64_t>()[i] + r0v[0]);
+                                for (int64_t i = 0; i < c2.numel(); ++i) idx.push_back(c2.data_ptr<int64_t>()[i] + r0v[1]);
+                            }
+                        }
+                        ns.push_back(n);
+                        if (!n) skipped.emplace_back((int64_t)t, (int64_t)d);
+                        rows.push_back(rows.back() + 2 * n);
+                    } else {
+                        int64_t B = 0;
+                        for (int v = 0; v < 2 && !a.t.empty(); ++v) {
+                            const at::Tensor& vp = a.t[5 * v + 2];
+                            if (v == 0) B = vp.numel() - 1;
+                            for (int64_t g = 0; g + 1 < vp.numel(); ++g) starts.push_back(vp.data_ptr<int64_t>()[g] + r0v[v]);
+                        }
+                        ns.push_back(B);
+                        rows.push_back(rows.back() + 2 * B);
+                    }
+                }
+                if (kind == 2) {
+                    out.add(out.a64, "nc_idx") = idx;
+                    lists["nc_rows"] = rows; lists["nc_n"] = ns;
+                } else {
+                    const int64_t B = (int64_t)starts.size();
+                    auto& pv = out.add(out.a32, "gc_ptr");
+                    pv = starts; pv.push_back(seg_ptr.back());
+                    auto& gid = out.add(out.a64, "gc_gid");
+                    if (B) gid.resize((size_t)(pv[B] - pv[0]));
+                    for (int64_t g = 0; g < B; ++g) std::fill(gid.begin() + (pv[g] - pv[0]), gid.begin() + (pv[g + 1] - pv[0]), g);
+                    lists["gc_rows"] = rows; lists["gc_n"] = ns;
+                    sc["gc_B"] = B; sc["gc_r0"] = task_row.back(); sc["gc_M"] = seg_ptr.back() - task_row.back();
+                }
+                sizes[t] = rows.back();
+            }
+            task_row.push_back(seg_ptr.back());
+        }
+        if (!err) {
+            const int64_t N = seg_ptr.back(), S = (int64_t)seg_dom.size();
+            sc["N"] = N; sc["S"] = S; sc["E"] = (int64_t)e_src.size();
+            int64_t max_seg = 0, max_seg_edges = 0;
+            for (int64_t i = 0; i < S; ++i) { max_seg = std::max(max_seg, seg_ptr[i + 1] - seg_ptr[i]); max_seg_edges = std::max(max_seg_edges, seg_edges[i]); }
+            sc["max_seg"] = max_seg; sc["max_seg_edges"] = max_seg_edges;
+            int64_t cut = 0;
+            if (want_split && S > 1) {
+                int64_t best = -1;
+                for (int64_t i = 1; i < S; ++i) {
+                    const int64_t dist = std::llabs(2 * seg_ptr[i] - N);
+                    if (best < 0 || dist < best) { best = dist; cut = i; }
+                }
+                if (!(seg_ptr[cut] > 0 && seg_ptr[cut] < N)) cut = 0;
+            }
+            sc["fwd_split_seg"] = cut; sc["fwd_split_row"] = cut ? seg_ptr[cut] : 0;
+            out.add(out.a32, "seg_ptr") = seg_ptr;
+            out.add(out.a32, "seg_dom") = seg_dom;
+            out.add(out.a32, "src_row") = src_rows;
+            auto& sep = out.add(out.a32, "seg_eptr");
+            sep.push_back(0);
+            for (int64_t i = 0; i < S; ++i) sep.push_back(sep.back() + seg_edges[i]);
+            auto& tiles = out.add(out.a32, "tiles");
+            int64_t ntiles = 0;
+            for (int64_t i = 0; i < S; ++i)
+                for (int64_t r = seg_ptr[i]; r < seg_ptr[i + 1]; r += 32) { tiles.push_back(i); tiles.push_back(r); ++ntiles; }
+            sc["num_tiles"] = ntiles;
+            auto& eall = out.add(out.a64, "edge_index");
+            eall = e_src; eall.insert(eall.end(), e_dst.begin(), e_dst.end());
+            if (!rowmask_at.empty()) {
+                auto& rm = out.add(out.a64, "rowmask");
+                rm.assign((size_t)N, 0);
+                for (size_t i = 0; i < rowmask_at.size(); ++i)
+                    std::memcpy(rm.data() + rowmask_at[i].first, rowmask_at[i].second, (size_t)rowmask_len[i] * sizeof(int64_t));
+            }
+        }
+    }
+    TORCH_CHECK(!err, err);
+    // ---- the two upload images: every array starts 16-byte aligned (int32: 4 elements, int64: 2)
+    pybind11::dict res;
+    auto pack = [&](std::vector<Img>& img, bool narrow, const char* key_img, const char* key_lay) {
+        const int64_t gran = narrow ? 4 : 2;
+        int64_t total = 0;
+        for (auto& a : img) total += ((int64_t)a.v.size() + gran - 1) / gran * gran;
+        at::Tensor cat = at::zeros({total}, narrow ? at::kInt : at::kLong);
+        pybind11::list lay;
+        int64_t o = 0;
+        for (auto& a : img) {
+            if (narrow) { int32_t* p = cat.data_ptr<int32_t>() + o; for (size_t i = 0; i < a.v.size(); ++i) p[i] = (int32_t)a.v[i]; }
+            else if (!a.v.empty()) std::memcpy(cat.data_ptr<int64_t>() + o, a.v.data(), a.v.size() * sizeof(int64_t));
+            lay.append(pybind11::make_tuple(a.name, o, (int64_t)a.v.size()));
+            o += ((int64_t)a.v.size() + gran - 1) / gran * gran;
+        }
+        res[key_img] = cat;
+        res[key_lay] = lay;
+    };
+    pack(out.a32, true, "cat32", "lay32");
+    pack(out.a64, false, "cat64", "lay64");
+    at::Tensor lab = at::empty({(int64_t)lp_labels.size()}, at::kFloat);
+    if (!lp_labels.empty()) std::memcpy(lab.data_ptr<float>(), lp_labels.data(), lp_labels.size() * sizeof(float));
+    res["lp_labels"] = lab;
+    res["seg_ptr"] = seg_ptr; res["seg_dom"] = seg_dom; res["seg_task"] = seg_task; res["task_row"] = task_row; res["sizes"] = sizes;
+    pybind11::list sk;
+    for (auto& x : skipped) sk.append(pybind11::make_tuple(x.first, x.second));
+    res["skipped"] = sk;
+    for (auto& kv : sc) res[kv.first.c_str()] = kv.second;
+    for (auto& kv : lists) res[kv.first.c_str()] = kv.second;
+    return res;
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -469,6 +774,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("getstate", &PyRandom::getstate)
         .def("negative_edges", &PyRandom::negative_edges, "batched_negative_sampling(to_undirected(pos), batch, num_neg_samples=E) of a domain batch");
     m.def("merge_mirrored_pairs", &merge_mirrored_pairs, "unordered pairs + signed multiplicities of a domain's positive and negative pairs");
+    m.def("plan_step", &plan_step, "the stacked layout and upload images of one step from draw_step's result, GIL released");
     m.def("draw_step", &draw_step, "all index artefacts of one step in the reference's order, one call");
     m.def("draw_views", &draw_views, "two augmented views of every graph of a batch, as index arrays");
 }

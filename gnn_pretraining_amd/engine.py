@@ -120,6 +120,32 @@ class StepPlan:
     pass
 
 
+class Artefacts(dict):
+    """draw()'s result {task: {domain: arrays}}; `raw` keeps the native module's own tuples (hostdraw.draw_step) for the native layout
+    step (hostdraw.plan_step), which then never touches the numpy copies."""
+    raw = None
+
+
+class _Views(dict):
+    """Named views into a packed upload image (StepPlan.a32 / a64 of a natively planned step), built on first use."""
+
+    def __init__(self, cat: np.ndarray, lay) -> None:
+        super().__init__()
+        self._cat, self._lay = cat, {n: (o, k) for n, o, k in lay}
+
+    _SHAPES = {"lp_edges": (2, -1), "edge_index": (2, -1), "tiles": (-1, 2)}
+
+    def __missing__(self, name):
+        o, k = self._lay[name]
+        v = self._cat[o:o + k]
+        v = v.reshape(self._SHAPES[name]) if name in self._SHAPES else v
+        self[name] = v
+        return v
+
+    def __contains__(self, name) -> bool:
+        return name in self._lay
+
+
 class ViewArrays:
     """One augmented view of a whole domain batch as flat index arrays (what Batch.from_data_list of the
     augmented graphs would hold, minus the features): rows = kept nodes (domain-local ids of the base batch),
@@ -229,6 +255,7 @@ class StepEngine:
         # score each unordered pair once (the scorer is symmetric in (src, dst)); GMP_LP_MERGE=0 keeps the reference's ordered list
         self.lp_merge = os.environ.get("GMP_LP_MERGE", "1") != "0"
         self.fwd_split = os.environ.get("GMP_FWD_SPLIT", "1") != "0"
+        self.native_plan = os.environ.get("GMP_NATIVE_PLAN", "1") != "0"
         for t in tasks:
             if t not in SUPPORTED_TASKS:
                 raise NotImplementedError(f"StepEngine covers {SUPPORTED_TASKS}; '{t}' runs on the module path")
@@ -466,7 +493,9 @@ class StepEngine:
             doms = inp.__dict__.get("_draw_args")
             if doms is None:
                 doms = inp.__dict__["_draw_args"] = [_host_tensors(b) + (int(b.x.size(1)),) for b in host.values()]
-            res = iter(H.draw_step(kinds, doms, gen, self._neg_native))
+            art = Artefacts()
+            art.raw = H.draw_step(kinds, doms, gen, self._neg_native)
+            res = iter(art.raw)
             for t in self.tasks:
                 if t not in self.DRAWN_TASKS:
                     continue
@@ -816,7 +845,43 @@ class StepEngine:
         return art
 
     # ---- plan: lay the step out as segments, everything as flat arrays ----------------------------------
+    def _plan_native(self, inp: StepInputs, raw) -> StepPlan:
+        """hostdraw.plan_step: the layout below in one native call with the GIL released (array for array the same: tests/test_hostdraw.py)."""
+        from ._step_desc import TASK_KIND
+        D = self.domains
+        doms = inp.__dict__.get("_draw_args")
+        if doms is None:
+            doms = inp.__dict__["_draw_args"] = [_host_tensors(inp.host[d]) + (int(inp.host[d].x.size(1)),) for d in D]
+        r = hostdraw().plan_step([TASK_KIND[t] for t in self.tasks], doms, [int(inp.row_off[d]) for d in D], raw, self.lp_merge, self.fwd_split,
+                                 H, GRAPH_PROPERTY_DIM)
+        p = StepPlan()
+        p.cat32, p.cat64 = r["cat32"].numpy(), r["cat64"].numpy()
+        p.lay32, p.lay64 = {n: o for n, o, _ in r["lay32"]}, {n: o for n, o, _ in r["lay64"]}
+        p.a32, p.a64 = _Views(p.cat32, r["lay32"]), _Views(p.cat64, r["lay64"])
+        p.seg_ptr, p.seg_dom, p.seg_task, p.task_row = r["seg_ptr"], r["seg_dom"], r["seg_task"], r["task_row"]
+        p.sizes = {t: int(v) for t, v in zip(self.tasks, r["sizes"])}
+        p.skipped = [(int(ti), D[int(di)]) for ti, di in r["skipped"]]
+        p.N, p.S, p.E, p.max_seg, p.max_seg_edges, p.num_tiles = r["N"], r["S"], r["E"], r["max_seg"], r["max_seg_edges"], r["num_tiles"]
+        p.fwd_split = (r["fwd_split_seg"], r["fwd_split_row"])
+        for k in ("nfm_rows", "nc_rows", "nc_n", "gc_rows", "gc_n", "gc_B", "gc_r0", "gc_M", "gp_rows", "gp_B", "gp_r0", "gp_M", "da_B", "da_r0", "da_M",
+                  "lp_K", "lp_S", "lp_rows_end", "lp_max_rows", "lp_max_edges"):
+            if k in r:
+                setattr(p, k, r[k])
+        if "lp_K" in r:
+            p.lp_labels = r["lp_labels"].numpy()
+            if p.lp_K > self.KMAX:
+                raise L.GnnmpError("engine: too many link-prediction edges")
+        if p.N > self.max_rows or p.E > self.max_edges or p.S > self.S_MAX:
+            raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
+                               f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
+        if p.cat32.size > getattr(self, "i32_cap", 1 << 62) or p.cat64.size > getattr(self, "i64_cap", 1 << 62):
+            raise L.GnnmpError("engine: staging buffer too small")
+        return p
+
     def plan(self, inp: StepInputs, art: Dict[str, object]) -> StepPlan:
+        raw = getattr(art, "raw", None)
+        if raw is not None and self.native_plan and hasattr(hostdraw(), "plan_step"):
+            return self._plan_native(inp, raw)
         p, D = StepPlan(), self.domains
         seg_ptr, seg_dom, seg_task = [0], [], []
         src_rows, edges, rowmasks = [], [], []

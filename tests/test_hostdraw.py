@@ -141,3 +141,59 @@ def test_merged_pairs_hold_the_ordered_list_as_a_multiset(monkeypatch):
             got = {(int(a), int(b)): int(sign * x) for a, b, x in zip(seg[0], seg[1], ws)}
             assert got == want and len(got) == seg.shape[1]
             assert list(got) == list(dict.fromkeys(keys))                              # first-occurrence order
+
+
+def _plan_fields(p):
+    names = ("N", "S", "E", "max_seg", "max_seg_edges", "num_tiles", "fwd_split", "seg_ptr", "seg_dom", "seg_task", "task_row", "sizes", "skipped",
+             "nfm_rows", "nc_rows", "nc_n", "gc_rows", "gc_n", "gc_B", "gc_r0", "gc_M", "gp_rows", "gp_B", "gp_r0", "gp_M", "da_B", "da_r0", "da_M",
+             "lp_K", "lp_S", "lp_rows_end", "lp_max_rows", "lp_max_edges")
+    out = {}
+    for n in names:
+        if hasattr(p, n):
+            v = getattr(p, n)
+            out[n] = [int(x) for x in v] if isinstance(v, (list, np.ndarray)) and n != "skipped" else (tuple(int(x) for x in v) if n == "fwd_split" else v)
+    return out
+
+
+@pytest.mark.parametrize("scheme", ["s4", "s5", "s1", "s2", "b3", "b2"])
+@pytest.mark.parametrize("merge,split", [(True, True), (False, False)])
+def test_native_layout_equals_the_python_layout(scheme, merge, split):
+    """hostdraw.plan_step (one call, GIL released) against engine.StepEngine.plan's numpy code on the same draws: every scalar, every
+    list, both upload images element for element and the offsets into them -- over the scheme families, with a domain that has no graph,
+    one with a single graph (no graph-contrast pair: tasks.py:241) and one with 1- and 2-node graphs."""
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from test_host_logic import _Inp, _planner
+    from gnn_pretraining_amd.engine import Artefacts
+    e = _planner("reference", scheme)
+    e.lp_merge, e.fwd_split = merge, split
+    gen = torch.Generator().manual_seed(13)
+    hosts = [S.pretrain_step_batches(gen, e.domains) for _ in range(3)]
+    odd = dict(hosts[0])
+    names = list(odd)
+    odd[names[0]] = Batch.empty(int(odd[names[0]].x.size(1)))
+    odd[names[1]] = Batch.from_data_list(hosts[1][names[1]].to_data_list()[:1])
+    if len(names) > 2:
+        F = int(odd[names[2]].x.size(1))
+        mk = lambda n, ei: Data(torch.zeros(n, F), ei, torch.zeros(1, dtype=torch.long), torch.zeros(12))
+        odd[names[2]] = Batch.from_data_list([mk(1, torch.zeros(2, 0, dtype=torch.long)), mk(2, torch.tensor([[0, 1], [1, 0]])),
+                                              S.random_graph(gen, F, 20.0, 30.0)])
+    hosts.append(odd)
+    for k, host in enumerate(hosts):
+        inp = _Inp(host)
+        art = e.draw(inp, torch.Generator().manual_seed(100 + k))
+        assert isinstance(art, Artefacts) and art.raw is not None
+        e.native_plan = True
+        pn = e.plan(inp, art)
+        e.native_plan = False
+        pp = e.plan(inp, art)
+        assert _plan_fields(pn) == _plan_fields(pp)
+        assert pn.lay32 == pp.lay32 and pn.lay64 == pp.lay64
+        assert pn.cat32.dtype == pp.cat32.dtype and np.array_equal(pn.cat32, pp.cat32)
+        assert pn.cat64.dtype == pp.cat64.dtype and np.array_equal(pn.cat64, pp.cat64)
+        if "link_pred" in e.tasks:
+            assert np.array_equal(pn.lp_labels, pp.lp_labels) and pn.lp_labels.dtype == np.float32
+        for name, arr in pp.a32.items():
+            assert np.array_equal(pn.a32[name], np.asarray(arr)) and pn.a32[name].shape == np.asarray(arr).shape, name
+        for name, arr in pp.a64.items():
+            assert np.array_equal(pn.a64[name], np.asarray(arr)) and pn.a64[name].shape == np.asarray(arr).shape, name
