@@ -122,8 +122,47 @@ class StepPlan:
 
 class Artefacts(dict):
     """draw()'s result {task: {domain: arrays}}; `raw` keeps the native module's own tuples (hostdraw.draw_step) for the native layout
-    step (hostdraw.plan_step), which then never touches the numpy copies."""
+    step (hostdraw.plan_step), which never touches the numpy copies -- so those are only built (`fill`) when somebody reads the dict
+    (tests, the oracle harness, the Python layout)."""
     raw = None
+    fill = None
+
+    def _need(self) -> None:
+        f, self.fill = self.fill, None
+        if f is not None:
+            f(self)
+
+    def __getitem__(self, k):
+        self._need()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._need()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._need()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._need()
+        return dict.__contains__(self, k)
+
+    def get(self, k, default=None):
+        self._need()
+        return dict.get(self, k, default)
+
+    def keys(self):
+        self._need()
+        return dict.keys(self)
+
+    def items(self):
+        self._need()
+        return dict.items(self)
+
+    def values(self):
+        self._need()
+        return dict.values(self)
 
 
 class _Views(dict):
@@ -495,22 +534,25 @@ class StepEngine:
                 doms = inp.__dict__["_draw_args"] = [_host_tensors(b) + (int(b.x.size(1)),) for b in host.values()]
             art = Artefacts()
             art.raw = H.draw_step(kinds, doms, gen, self._neg_native)
-            res = iter(art.raw)
-            for t in self.tasks:
-                if t not in self.DRAWN_TASKS:
-                    continue
-                row, art[t] = next(res), {}
-                for d, r in zip(host, row):
-                    if r is None:
-                        art[t][d] = None
-                    elif len(r) == 0:
-                        art[t][d] = _EMPTY_ART[t]()
-                    elif len(r) == 1:
-                        art[t][d] = r[0].numpy()
-                    else:
-                        art[t][d] = tuple(ViewArrays(*(x.numpy() for x in r[5 * v:5 * v + 3]),
-                                                     r[5 * v + 3].numpy().view(np.uint64) if r[5 * v + 3].numel() else None, r[5 * v + 4].numpy())
-                                          for v in range(2))
+            tasks, names = [t for t in self.tasks if t in self.DRAWN_TASKS], list(host)
+
+            def fill(a: Artefacts) -> None:
+                for t, row in zip(tasks, a.raw):
+                    out = {}
+                    for d, r in zip(names, row):
+                        if r is None:
+                            out[d] = None
+                        elif len(r) == 0:
+                            out[d] = _EMPTY_ART[t]()
+                        elif len(r) == 1:
+                            out[d] = r[0].numpy()
+                        else:
+                            out[d] = tuple(ViewArrays(*(x.numpy() for x in r[5 * v:5 * v + 3]),
+                                                      r[5 * v + 3].numpy().view(np.uint64) if r[5 * v + 3].numel() else None, r[5 * v + 4].numpy())
+                                           for v in range(2))
+                    dict.__setitem__(a, t, out)
+
+            art.fill = fill
             return art
         if H is not None:
             args = {d: _host_tensors(b) for d, b in host.items() if b.num_graphs}
