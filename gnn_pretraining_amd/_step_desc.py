@@ -43,7 +43,7 @@ class StepDesc(C.Structure):
                 ("csr", p * 6), ("csr_status", p), ("csr_ws", p), ("csr_ws_bytes", sz),
                 ("lp_csr", p * 6), ("lp_csr_status", p), ("lp_csr_ws", p), ("lp_csr_ws_bytes", sz),
                 ("lp_seg_ptr", p), ("lp_seg_eptr", p), ("lp_S", i32), ("lp_max_seg_rows", i64), ("lp_max_seg_edges", i64), ("lp_rows_end", i64),
-                ("fwd_split_seg", i32), ("fwd_split_row", i32),
+                ("fwd_cut_seg", i32 * 2), ("fwd_cut_row", i32 * 2),
                 ("flat", p), ("P", i64), ("task_grads", p),
                 ("x_all", p), ("x_rows", i64),
                 ("enc_off_w", i64 * MAXD), ("enc_off_b", i64 * MAXD), ("enc_d_in", i32 * MAXD),

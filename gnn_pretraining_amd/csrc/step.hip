@@ -20,8 +20,8 @@ constexpr int NEV = 4 + 2 * GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS + 9;
 constexpr int EV_LAYER0_DONE = NEV - 4, EV_HEADS_DONE = NEV - 3, EV_BWD_DONE = NEV - 2;
 constexpr int EV_HEAD_PARAMS = 4 + GMP_STEP_MAX_TASKS + 4 * GMP_STEP_LAYERS;   // [task], [MAX_TASKS] = the heads of the main stream: weight-gradient GEMMs done
 constexpr int EV_MAIN_HEADS = EV_HEAD_PARAMS + GMP_STEP_MAX_TASKS + 1;           // main: input halves of its own heads done
-constexpr int EV_FWD_FORK = EV_MAIN_HEADS + 1, EV_FWD_JOIN = EV_MAIN_HEADS + 2;  // split forward: main -> second stream, and back
-static_assert(EV_FWD_JOIN < NEV - 4, "event pool too small");
+constexpr int EV_FWD_FORK = EV_MAIN_HEADS + 1, EV_FWD_JOIN = EV_MAIN_HEADS + 2;  // split forward: main -> the other streams, and back [2]
+static_assert(EV_FWD_JOIN + 1 < NEV - 4, "event pool too small");
 // ev[NEV - 1]: running statistics done (aux)
 
 // Gate flags (d.sync_flags, int32[64], all compared against the step's epoch): the same dependencies as the events above, carried
@@ -41,7 +41,7 @@ enum {
     F_AUX_DONE = 37,                   // aux -> main: everything aux did for this step is done
     F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
     F_FWD_FORK = 39,                   // main -> the second forward stream: encoders done (split forward)
-    F_FWD_JOIN = 40,                   // second forward stream -> main: its half of the stacked forward is done
+    F_FWD_JOIN = 40,                   // [2] the other forward streams -> main: their row range of the stacked forward is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
@@ -389,27 +389,51 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     (void)hipStreamWaitEvent(main, ev[1], 0);
     if (timing) (void)hipEventRecord(phase_events()[1], main);
 
-    // ---- stacked backbone forward: one pass on main, or two row ranges on two streams (gnnmp_step.h fwd_split_*)
-    hipStream_t fwd_b = main;
-    for (int ti = 0; ti < T; ++ti) {
+    // ---- stacked backbone forward: one pass on main, or up to three row ranges on as many streams (gnnmp_step.h fwd_cut_*)
+    hipStream_t fwd_streams[3] = {main, main, main};
+    int extra = 0;
+    for (int ti = 0; ti < T && extra < 2; ++ti) {
         hipStream_t ts = (hipStream_t)task_streams[ti];
-        if (ts != main && ts != aux) { fwd_b = ts; break; }
+        if (ts != main && ts != aux && ts != fwd_streams[1]) fwd_streams[++extra] = ts;
     }
     const size_t bn_fwd_slice = gmp_bn_workspace_bytes(N, 2 * H, d.S, d.max_seg);
-    // (both ranges at least 1,024 rows: below that gmp_gemm_f32 runs its first kernel, whose K order differs from the pipelined one the
-    // single pass uses -- the split must not change a bit -- and a step that small has nothing to hide behind anyway)
-    const bool split_fwd = d.fwd_split_seg > 0 && d.fwd_split_seg < d.S && d.fwd_split_row >= 1024 && N - d.fwd_split_row >= 1024 && fwd_b != main &&
-                           d.bn_ws_bytes >= 2 * bn_fwd_slice && N < 65536;
     struct Range { int s0, s1; int64_t r0, r1; hipStream_t st; void* ws; };
-    Range ranges[2] = {{0, split_fwd ? d.fwd_split_seg : d.S, 0, split_fwd ? d.fwd_split_row : N, main, d.bn_ws},
-                       {d.fwd_split_seg, d.S, d.fwd_split_row, N, fwd_b, (char*)d.bn_ws + bn_fwd_slice}};
+    Range ranges[3];
+    int nranges = 1;
+    ranges[0] = Range{0, d.S, 0, N, main, d.bn_ws};
+    {
+        // (every range at least 1,024 rows: below that gmp_gemm_f32 runs its first kernel, whose K order differs from the pipelined one the
+        // single pass uses -- the split must not change a bit -- and a step that small has nothing to hide behind anyway)
+        int cuts = 0;
+        int64_t prev_row = 0;
+        int prev_seg = 0;
+        bool ok = N < 65536;
+        for (int k = 0; k < 2 && ok; ++k) {
+            if (d.fwd_cut_seg[k] <= 0) break;
+            ok = d.fwd_cut_seg[k] > prev_seg && d.fwd_cut_seg[k] < d.S && d.fwd_cut_row[k] - prev_row >= 1024 && N - d.fwd_cut_row[k] >= 1024;
+            prev_seg = d.fwd_cut_seg[k]; prev_row = d.fwd_cut_row[k];
+            ++cuts;
+        }
+        if (ok && cuts > 0 && cuts <= extra && d.bn_ws_bytes >= (size_t)(cuts + 1) * bn_fwd_slice) {
+            nranges = cuts + 1;
+            for (int k = 0; k < nranges; ++k) {
+                ranges[k].s0 = k ? d.fwd_cut_seg[k - 1] : 0;
+                ranges[k].s1 = k + 1 < nranges ? d.fwd_cut_seg[k] : d.S;
+                ranges[k].r0 = k ? d.fwd_cut_row[k - 1] : 0;
+                ranges[k].r1 = k + 1 < nranges ? d.fwd_cut_row[k] : N;
+                ranges[k].st = fwd_streams[k];
+                ranges[k].ws = (char*)d.bn_ws + (size_t)k * bn_fwd_slice;
+            }
+        }
+    }
+    const bool split_fwd = nranges > 1;
     if (split_fwd) {
         GMP_TRY(signal(F_FWD_FORK, ev[EV_FWD_FORK], main));
-        GMP_TRY(await(F_FWD_FORK, ev[EV_FWD_FORK], fwd_b));
+        for (int k = 1; k < nranges; ++k) GMP_TRY(await(F_FWD_FORK, ev[EV_FWD_FORK], ranges[k].st));
     }
     for (int l = 0; l < GMP_STEP_LAYERS; ++l) {
         const gmp_layer_desc& L = d.layer[l];
-        for (int k = 0; k < (split_fwd ? 2 : 1); ++k) {
+        for (int k = 0; k < nranges; ++k) {
             const Range& R = ranges[k];
             gmp_stream_t st = (gmp_stream_t)R.st;
             const int64_t M = R.r1 - R.r0;
@@ -430,8 +454,12 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (timing && l + 1 < GMP_STEP_LAYERS) (void)hipEventRecord(phase_events()[2 + l], main);
     }
     if (split_fwd) {
-        GMP_TRY(signal(F_FWD_JOIN, ev[EV_FWD_JOIN], fwd_b));
-        GMP_TRY(await(F_FWD_JOIN, ev[EV_FWD_JOIN], main));
+        for (int k = 1; k < nranges; ++k) GMP_TRY(signal(F_FWD_JOIN + k - 1, ev[EV_FWD_JOIN + k - 1], ranges[k].st));
+        if (gates) {
+            GMP_TRY(gmp_gate_wait(d.sync_flags, (nranges > 2 ? 3ull : 1ull) << F_FWD_JOIN, d.epoch, d.sync_flags + F_ERR, main_));
+        } else {
+            for (int k = 1; k < nranges; ++k) (void)hipStreamWaitEvent(main, ev[EV_FWD_JOIN + k - 1], 0);
+        }
     }
 
     // ---- task heads, each on its own stream

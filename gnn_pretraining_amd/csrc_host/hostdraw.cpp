@@ -492,7 +492,7 @@ struct PlanOut {
 }  // namespace
 
 pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, int64_t>> doms,
-                         std::vector<int64_t> row_off, pybind11::list art, bool lp_merge, bool want_split, int64_t hidden, int64_t prop_dim) {
+                         std::vector<int64_t> row_off, pybind11::list art, bool lp_merge, int64_t fwd_ranges, int64_t hidden, int64_t prop_dim) {
     const size_t T = kinds.size(), D = doms.size();
     TORCH_CHECK(row_off.size() == D, "plan_step: one row offset per domain");
     // ---- unpack the artefacts while the GIL is held (tensor handles only)
@@ -702,16 +702,19 @@ pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
             int64_t max_seg = 0, max_seg_edges = 0;
             for (int64_t i = 0; i < S; ++i) { max_seg = std::max(max_seg, seg_ptr[i + 1] - seg_ptr[i]); max_seg_edges = std::max(max_seg_edges, seg_edges[i]); }
             sc["max_seg"] = max_seg; sc["max_seg_edges"] = max_seg_edges;
-            int64_t cut = 0;
-            if (want_split && S > 1) {
-                int64_t best = -1;
+            // the stacked forward runs as `fwd_ranges` row ranges on as many streams (gnnmp_step.h fwd_cut_*): cut k at the segment boundary
+            // nearest k N / R, kept only while the cuts ascend strictly inside (0, N)
+            std::vector<int64_t> cut_seg, cut_row;
+            for (int64_t k = 1; k < fwd_ranges && S > 1; ++k) {
+                int64_t best = -1, cut = 0;
                 for (int64_t i = 1; i < S; ++i) {
-                    const int64_t dist = std::llabs(2 * seg_ptr[i] - N);
+                    const int64_t dist = std::llabs(fwd_ranges * seg_ptr[i] - k * N);
                     if (best < 0 || dist < best) { best = dist; cut = i; }
                 }
-                if (!(seg_ptr[cut] > 0 && seg_ptr[cut] < N)) cut = 0;
+                const int64_t prev = cut_row.empty() ? 0 : cut_row.back();
+                if (seg_ptr[cut] > prev && seg_ptr[cut] < N) { cut_seg.push_back(cut); cut_row.push_back(seg_ptr[cut]); }
             }
-            sc["fwd_split_seg"] = cut; sc["fwd_split_row"] = cut ? seg_ptr[cut] : 0;
+            lists["fwd_cut_seg"] = cut_seg; lists["fwd_cut_row"] = cut_row;
             out.add(out.a32, "seg_ptr") = seg_ptr;
             out.add(out.a32, "seg_dom") = seg_dom;
             out.add(out.a32, "src_row") = src_rows;

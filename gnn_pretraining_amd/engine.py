@@ -293,7 +293,9 @@ class StepEngine:
         self._neg_native = None
         # score each unordered pair once (the scorer is symmetric in (src, dst)); GMP_LP_MERGE=0 keeps the reference's ordered list
         self.lp_merge = os.environ.get("GMP_LP_MERGE", "1") != "0"
-        self.fwd_split = os.environ.get("GMP_FWD_SPLIT", "1") != "0"
+        # row ranges of the stacked forward (gnnmp_step.h fwd_cut_*): 1 = one pass on main (GMP_FWD_SPLIT=0 is the old spelling), 2 the
+        # default, 3 measured equal or slightly worse (1.474-1.484 against 1.455-1.485 ms per step)
+        self.fwd_ranges = 1 if os.environ.get("GMP_FWD_SPLIT", "1") == "0" else max(1, min(3, int(os.environ.get("GMP_FWD_RANGES", "2"))))
         self.native_plan = os.environ.get("GMP_NATIVE_PLAN", "1") != "0"
         for t in tasks:
             if t not in SUPPORTED_TASKS:
@@ -894,7 +896,7 @@ class StepEngine:
         doms = inp.__dict__.get("_draw_args")
         if doms is None:
             doms = inp.__dict__["_draw_args"] = [_host_tensors(inp.host[d]) + (int(inp.host[d].x.size(1)),) for d in D]
-        r = hostdraw().plan_step([TASK_KIND[t] for t in self.tasks], doms, [int(inp.row_off[d]) for d in D], raw, self.lp_merge, self.fwd_split,
+        r = hostdraw().plan_step([TASK_KIND[t] for t in self.tasks], doms, [int(inp.row_off[d]) for d in D], raw, self.lp_merge, self.fwd_ranges,
                                  H, GRAPH_PROPERTY_DIM)
         p = StepPlan()
         p.cat32, p.cat64 = r["cat32"].numpy(), r["cat64"].numpy()
@@ -904,7 +906,7 @@ class StepEngine:
         p.sizes = {t: int(v) for t, v in zip(self.tasks, r["sizes"])}
         p.skipped = [(int(ti), D[int(di)]) for ti, di in r["skipped"]]
         p.N, p.S, p.E, p.max_seg, p.max_seg_edges, p.num_tiles = r["N"], r["S"], r["E"], r["max_seg"], r["max_seg_edges"], r["num_tiles"]
-        p.fwd_split = (r["fwd_split_seg"], r["fwd_split_row"])
+        p.fwd_cuts = list(zip(r["fwd_cut_seg"], r["fwd_cut_row"]))
         for k in ("nfm_rows", "nc_rows", "nc_n", "gc_rows", "gc_n", "gc_B", "gc_r0", "gc_M", "gp_rows", "gp_B", "gp_r0", "gp_M", "da_B", "da_r0", "da_M",
                   "lp_K", "lp_S", "lp_rows_end", "lp_max_rows", "lp_max_edges"):
             if k in r:
@@ -1039,9 +1041,15 @@ class StepEngine:
         e_all = np.concatenate(edges, axis=1)
         p.E = e_all.shape[1]
         p.max_seg = max(b - a for a, b in zip(seg_ptr[:-1], seg_ptr[1:]))
-        # the stacked forward runs as two row ranges on two streams (gnnmp_step.h fwd_split_*): cut at the segment boundary nearest N / 2
-        cut = min(range(1, p.S), key=lambda i: abs(2 * seg_ptr[i] - p.N)) if p.S > 1 and self.fwd_split else 0
-        p.fwd_split = (cut, seg_ptr[cut]) if cut and 0 < seg_ptr[cut] < p.N else (0, 0)
+        # the stacked forward runs as fwd_ranges row ranges on as many streams (gnnmp_step.h fwd_cut_*): cut k at the segment boundary nearest
+        # k N / R, kept only while the cuts ascend strictly inside (0, N)
+        p.fwd_cuts, R = [], self.fwd_ranges
+        for k in range(1, R):
+            if p.S <= 1:
+                break
+            cut = min(range(1, p.S), key=lambda i: abs(R * seg_ptr[i] - k * p.N))
+            if (p.fwd_cuts[-1][1] if p.fwd_cuts else 0) < seg_ptr[cut] < p.N:
+                p.fwd_cuts.append((cut, seg_ptr[cut]))
         if p.N > self.max_rows or p.E > self.max_edges or p.S > self.S_MAX:
             raise L.GnnmpError(f"step of {p.N} rows / {p.E} edges / {p.S} segments exceeds the engine capacity "
                                f"({self.max_rows}/{self.max_edges}/{self.S_MAX})")
@@ -1870,7 +1878,8 @@ class StepEngine:
         D = self.domains
         d.N, d.E, d.S, d.max_seg, d.num_tiles = p.N, p.E, p.S, p.max_seg, p.num_tiles
         d.max_seg_edges, d.seg_eptr = p.max_seg_edges, p.d32["seg_eptr"]
-        d.fwd_split_seg, d.fwd_split_row = p.fwd_split
+        for k in range(2):
+            d.fwd_cut_seg[k], d.fwd_cut_row[k] = p.fwd_cuts[k] if k < len(p.fwd_cuts) else (0, 0)
         d.training, d.dropout_p = int(self.model.training), float(self.dropout_p)
         d.dp_exchange = int(self.grad_sync is not None or self.parts_beside_backward)     # publish when each part's gradients are final
         d.upload_on_aux = int(self.upload_on_aux)

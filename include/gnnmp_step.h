@@ -105,11 +105,12 @@ typedef struct {
        workgroup per (domain, orientation) -- gmp_csr_build_segmented over rows [0, lp_rows_end) -- instead of one workgroup for all
        ~30 k edges (0.49 ms).  lp_S = 0: whole-batch build. */
     const int32_t *lp_seg_ptr, *lp_seg_eptr; int32_t lp_S; int64_t lp_max_seg_rows, lp_max_seg_edges, lp_rows_end;
-    /* Stacked forward in two halves: segments [0, fwd_split_seg) = rows [0, fwd_split_row) on main, the rest on one of the task
-       streams (idle until the heads), so one half's latency-bound BatchNorm / aggregation launches run beside the other half's GEMMs.
-       Segments are independent through the backbone (per-segment statistics, block-diagonal adjacency), every kernel is
-       element-wise identical under a row split: the result is bit-identical to the unsplit forward.  0 = one pass on main. */
-    int32_t fwd_split_seg, fwd_split_row;
+    /* Stacked forward in up to three row ranges: cut k (k = 0, 1) ends a range at segment fwd_cut_seg[k] = row fwd_cut_row[k]
+       (ascending; 0 = no cut).  The first range runs on main, the others on task streams (idle until the heads), so one range's
+       latency-bound BatchNorm / aggregation launches run beside the others' GEMMs.  Segments are independent through the backbone
+       (per-segment statistics, block-diagonal adjacency) and every kernel is element-wise identical under a row split: the result is
+       bit-identical to the single pass.  Ignored (one pass on main) unless every range keeps at least 1,024 rows. */
+    int32_t fwd_cut_seg[2], fwd_cut_row[2];
     /* parameters and per-task gradients */
     float* flat; int64_t P; float* task_grads;
     /* encoders */

@@ -241,33 +241,33 @@ def test_native_executor_is_bitwise_identical_to_the_python_launch_sequence(sche
 
 
 @pytest.mark.parametrize("scheme,gates", [("s4", "1"), ("s4", "0"), ("s1", "1"), ("s2", "1"), ("b3", "1")])
-def test_forward_in_two_row_ranges_gives_the_same_bits(monkeypatch, scheme, gates):
-    """gnnmp_step.h fwd_split_*: the stacked forward cut at a segment boundary and run on two streams (main + a task stream) against
-    the single pass -- segments are independent through the backbone and every kernel is element-wise identical under a row split,
-    so three optimisation steps with dropout on leave the same parameters, gradients, losses and running statistics, bit for bit;
-    with gates and with events (the fork / join use either).  b3 (1,690 rows) is below the size the step splits at: one pass either way."""
+def test_forward_in_row_ranges_gives_the_same_bits(monkeypatch, scheme, gates):
+    """gnnmp_step.h fwd_cut_*: the stacked forward cut at segment boundaries and run on two or three streams (main + task streams)
+    against the single pass -- segments are independent through the backbone and every kernel is element-wise identical under a row
+    split, so three optimisation steps with dropout on leave the same parameters, gradients, losses and running statistics, bit for
+    bit; with gates and with events (the fork / joins use either).  s1 (2,112 rows) has room for two ranges of 1,024 rows, b3 (1,690)
+    for none: the step falls back by itself."""
     outs = []
-    for split in (True, False):
+    for ranges in (3, 2, 1):
         monkeypatch.setenv("GMP_STEP_GATES", gates)
         _, hm, eng, host, inp, gen, tasks, _ = build(scheme, 83)
         if gates == "1" and not eng.use_gates:
             pytest.skip("no hardware queue per stream on this box")
-        eng.fwd_split, eng.dropout_p, eng.grl_lambda = split, 0.2, 0.004
+        eng.fwd_ranges, eng.dropout_p, eng.grl_lambda = ranges, 0.2, 0.004
         g = torch.Generator().manual_seed(6)
         for _ in range(3):
             eng.step(inp, g, order=list(tasks))
-        if split:
-            assert eng.last_plan.fwd_split[0] > 0 and 0 < eng.last_plan.fwd_split[1] < eng.last_plan.N
-        else:
-            assert eng.last_plan.fwd_split == (0, 0)
+        cuts = eng.last_plan.fwd_cuts
+        assert len(cuts) == ranges - 1 and all(0 < r < eng.last_plan.N for _, r in cuts) and cuts == sorted(cuts)
         eng.check_gates()
         torch.cuda.synchronize()
         outs.append((eng.flat.clone(), eng.task_grads.clone(), eng.loss_sums.clone(), eng.h[-1][:eng.last_plan.N].clone(),
                      {k: v.clone() for k, v in hm.state_dict().items() if "running_" in k}))
-    for a, b, what in zip(outs[0][:4], outs[1][:4], ("parameters", "per-task gradients", "loss sums", "backbone output")):
-        assert torch.equal(a, b), what
-    for k in outs[0][4]:
-        assert torch.equal(outs[0][4][k], outs[1][4][k]), k
+    for o in outs[:2]:
+        for a, b, what in zip(o[:4], outs[2][:4], ("parameters", "per-task gradients", "loss sums", "backbone output")):
+            assert torch.equal(a, b), what
+        for k in o[4]:
+            assert torch.equal(o[4][k], outs[2][4][k]), k
 
 
 @pytest.mark.parametrize("scheme", ["s4", "s5", "b2"])

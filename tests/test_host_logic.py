@@ -68,7 +68,7 @@ def _planner(mode, scheme="s4"):
     e.tasks, e.domains = PT.ACTIVE_TASKS[scheme], PT.PRETRAIN_DOMAINS[scheme]
     e.max_rows, e.max_edges, e.S_MAX, e.KMAX, e.rng_mode, e._nprng = 16384, 131072, 64, 131072, mode, None
     import random
-    e.neg_rng, e._neg_native, e.lp_merge, e.fwd_split, e.native_plan = random.Random(99), None, True, True, True
+    e.neg_rng, e._neg_native, e.lp_merge, e.fwd_ranges, e.native_plan = random.Random(99), None, True, 2, True
     return e
 
 

@@ -144,19 +144,19 @@ def test_merged_pairs_hold_the_ordered_list_as_a_multiset(monkeypatch):
 
 
 def _plan_fields(p):
-    names = ("N", "S", "E", "max_seg", "max_seg_edges", "num_tiles", "fwd_split", "seg_ptr", "seg_dom", "seg_task", "task_row", "sizes", "skipped",
+    names = ("N", "S", "E", "max_seg", "max_seg_edges", "num_tiles", "fwd_cuts", "seg_ptr", "seg_dom", "seg_task", "task_row", "sizes", "skipped",
              "nfm_rows", "nc_rows", "nc_n", "gc_rows", "gc_n", "gc_B", "gc_r0", "gc_M", "gp_rows", "gp_B", "gp_r0", "gp_M", "da_B", "da_r0", "da_M",
              "lp_K", "lp_S", "lp_rows_end", "lp_max_rows", "lp_max_edges")
     out = {}
     for n in names:
         if hasattr(p, n):
             v = getattr(p, n)
-            out[n] = [int(x) for x in v] if isinstance(v, (list, np.ndarray)) and n != "skipped" else (tuple(int(x) for x in v) if n == "fwd_split" else v)
+            out[n] = [int(x) for x in v] if isinstance(v, (list, np.ndarray)) and n not in ("skipped", "fwd_cuts") else ([tuple(int(y) for y in x) for x in v] if n == "fwd_cuts" else v)
     return out
 
 
 @pytest.mark.parametrize("scheme", ["s4", "s5", "s1", "s2", "b3", "b2"])
-@pytest.mark.parametrize("merge,split", [(True, True), (False, False)])
+@pytest.mark.parametrize("merge,split", [(True, 3), (False, 1), (True, 2)])
 def test_native_layout_equals_the_python_layout(scheme, merge, split):
     """hostdraw.plan_step (one call, GIL released) against engine.StepEngine.plan's numpy code on the same draws: every scalar, every
     list, both upload images element for element and the offsets into them -- over the scheme families, with a domain that has no graph,
@@ -166,7 +166,7 @@ def test_native_layout_equals_the_python_layout(scheme, merge, split):
     from test_host_logic import _Inp, _planner
     from gnn_pretraining_amd.engine import Artefacts
     e = _planner("reference", scheme)
-    e.lp_merge, e.fwd_split = merge, split
+    e.lp_merge, e.fwd_ranges = merge, split
     gen = torch.Generator().manual_seed(13)
     hosts = [S.pretrain_step_batches(gen, e.domains) for _ in range(3)]
     odd = dict(hosts[0])
