@@ -105,14 +105,21 @@ __device__ __forceinline__ void stats_for(const BnArgs& a, int s, int c, float4*
 // ONCE with every load in flight together, instead of three latency-bound sweeps.
 constexpr int SCOLS = 32, SCQ = SCOLS / 4, SRL = THREADS / SCQ;   // 8 quads x 32 row lanes
 
+// Column sum over the RL_ row lanes of a (segment, 32 columns) block: thread (rl, cq) sits at threadIdx.x = rl * 8 + cq, so a wave holds
+// eight row lanes of every column quad -- three shuffle steps fold those, the RL_ / 8 waves meet in LDS.  (The first version summed RL_
+// LDS entries per thread: a 32- or 64-deep chain of dependent reads, twice per BatchNorm forward, on the step's critical path.)
 template <int RL_, int CQ_>
 __device__ __forceinline__ float4 colsum_t(float4 v, float4 (*sh)[CQ_], int rl, int cq) {
-    __syncthreads();
-    sh[rl][cq] = v;
+    static_assert(CQ_ == 8 && RL_ % 8 == 0, "layout: 8 column quads x RL_ row lanes, 8 row lanes per wave");
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+        v = make_float4(v.x + __shfl_xor(v.x, o, 64), v.y + __shfl_xor(v.y, o, 64), v.z + __shfl_xor(v.z, o, 64), v.w + __shfl_xor(v.w, o, 64));
+    __syncthreads();                                  // (sh may still be read from the previous call)
+    if ((rl & 7) == 0) sh[rl >> 3][cq] = v;
     __syncthreads();
     float4 s = sh[0][cq];
 #pragma unroll
-    for (int i = 1; i < RL_; ++i) s = add4(s, sh[i][cq]);
+    for (int i = 1; i < RL_ / 8; ++i) s = add4(s, sh[i][cq]);
     return s;
 }
 
@@ -450,7 +457,9 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
 // WIDE: 64 row lanes (512 threads) and half the rows per thread for the same (segment, 32 columns) tile.  The backward kernel
 // at 16 rows per thread needs 204 VGPRs: beside the resident blocks of the weight-gradient GEMM it runs next to in the step
 // (4 waves x 60 VGPRs per SIMD) only ONE such wave fits per SIMD, half the workgroups wait for a slot and the kernel takes
-// 31 us instead of the 15 us it takes alone; at 8 rows per thread two waves fit.  GMP_BN_WIDE=0/1 overrides (A/B aid).
+// 31 us instead of the 15 us it takes alone; at 8 rows per thread two waves fit.  The forward takes the wide form too since the
+// column sums fold by shuffles (1.420 -> 1.405 ms per step; 1,024-thread blocks: no further gain).  GMP_BN_WIDE = bit 0 backward,
+// bit 1 forward (A/B aid; default 3).
 #define GMP_BN_SHORT_LAUNCH(KERNEL, MAXROWS, GRID, BLK, ST, ARGS, WIDE)                \
     do {                                                                               \
         if (WIDE) {                                                                    \
@@ -488,7 +497,7 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(0) & 2) != 0);
+        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 2) != 0);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         if (cfg->training) {
@@ -635,7 +644,7 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(1) & 1) != 0);
+        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 1) != 0);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, blk, 0, st, a);
