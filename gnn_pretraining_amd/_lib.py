@@ -144,6 +144,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_step_wait_grads": (C.c_int, [i32, p]),
     "gmp_step_phase_ms": (C.c_int, [p]),
     "gmp_step_phase_detail_ms": (C.c_int, [p]),
+    "gmp_step_head_ms": (C.c_int, [p, i32]),
     "gmp_mt_workspace_bytes": (sz, [i32]),
     "gmp_mt_pcgrad_clip_adamw": (C.c_int, [p, i64, i32, i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, p, f32, f32, f32,
                                            f32, p, p, p, p, p, sz, i32, p]),

@@ -72,6 +72,19 @@ hipEvent_t* phase_events() {
     }
     return ev;
 }
+// (diagnostic) per head: its stream at the start of the head, after the input-gradient half, after the weight-gradient half; all against
+// the main stream's "forward done" event
+hipEvent_t* head_events() {
+    static hipEvent_t ev[3 * GMP_STEP_MAX_TASKS];
+    static bool made = false;
+    if (!made) {
+        for (int i = 0; i < 3 * GMP_STEP_MAX_TASKS; ++i) (void)hipEventCreate(&ev[i]);
+        made = true;
+    }
+    return ev;
+}
+int g_head_tasks = 0;
+bool g_head_recorded[3 * GMP_STEP_MAX_TASKS] = {false};
 bool phase_timing() {
     static const bool on = getenv("GMP_STEP_TIMING") != nullptr;
     return on;
@@ -471,6 +484,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // waits for the input-gradient half only; the weight-gradient GEMMs (they only feed task_grads) follow on the head's own
     // stream and run beside the first layers of the stacked backward.  The heads that live on main hand theirs to `helper`.
     float* head_d1[GMP_STEP_MAX_TASKS] = {nullptr};
+    g_head_tasks = T;
     hipStream_t helper = main;
     for (int ti = 0; ti < T; ++ti) {
         hipStream_t ts = (hipStream_t)task_streams[ti];
@@ -483,11 +497,14 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             if ((ts == main) != (pass == 1)) continue;
             if (ts != main) GMP_TRY(await(F_FWD, ev[3], ts));
             if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
+            if (timing) { (void)hipEventRecord(head_events()[3 * ti], ts); g_head_recorded[3 * ti] = true; g_head_recorded[3 * ti + 2] = false; }
             GMP_TRY(task_head_inputs(d, ti, task_streams[ti], &head_d1[ti]));
+            if (timing) { (void)hipEventRecord(head_events()[3 * ti + 1], ts); g_head_recorded[3 * ti + 1] = true; }
             if (ts != main) {
                 signal_by_gemm(F_HEAD_IN + ti, ev[4 + ti], ts);          // the head's first weight-gradient GEMM opens main's gate
                 GMP_TRY(task_head_params(d, ti, task_streams[ti], head_d1[ti]));
                 GMP_TRY(signal_flush(F_HEAD_IN + ti, ts));
+                if (timing) { (void)hipEventRecord(head_events()[3 * ti + 2], ts); g_head_recorded[3 * ti + 2] = true; }
                 if (!lean) (void)hipEventRecord(ev[EV_HEAD_PARAMS + ti], ts);       // main joins these before the tail: long complete by then
                 if (gates) {
                     GMP_TRY(gmp_gate_open(d.sync_flags + F_HEAD_PARAMS + ti, d.epoch, task_streams[ti]));
@@ -734,5 +751,19 @@ extern "C" int gmp_step_phase_detail_ms(float* out) {
     if (hipEventSynchronize(e[GMP_STEP_PHASES]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_detail_ms: no step recorded");
     for (int i = 0; i < GMP_STEP_PHASES; ++i)
         if (hipEventElapsedTime(&out[i], e[i], e[i + 1]) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "step_phase_detail_ms: elapsed");
+    return GMP_OK;
+}
+
+// (diagnostic, GMP_STEP_TIMING=1) per task: ms from "stacked forward done" to the head's start, to the end of its input-gradient half and
+// to the end of its weight-gradient half (0 where the head runs on the main stream and has no separate second half) -- out[3 * task + k]
+extern "C" int gmp_step_head_ms(float* out, int max_tasks) {
+    if (!out || max_tasks < g_head_tasks) return gmp::fail(GMP_ERR_ARG, "step_head_ms: bad argument");
+    if (!phase_timing()) return gmp::fail(GMP_ERR_UNSUPPORTED, "step_head_ms: set GMP_STEP_TIMING=1 before the first step");
+    hipEvent_t fwd_done = phase_events()[1 + GMP_STEP_LAYERS];
+    (void)hipEventSynchronize(phase_events()[GMP_STEP_PHASES]);
+    for (int i = 0; i < 3 * g_head_tasks; ++i) {
+        out[i] = 0.f;
+        if (g_head_recorded[i] && hipEventSynchronize(head_events()[i]) == hipSuccess) (void)hipEventElapsedTime(&out[i], fwd_done, head_events()[i]);
+    }
     return GMP_OK;
 }

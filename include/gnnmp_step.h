@@ -159,6 +159,9 @@ int gmp_step_phase_ms(float* out3);
  * layers 4..0, below-backbone tail (mask token + encoder backward). */
 #define GMP_STEP_PHASES (2 * GMP_STEP_LAYERS + 3)
 int gmp_step_phase_detail_ms(float* out);
+/* (diagnostic) per task: ms from "stacked forward done" to the head's start / end of its input-gradient half / end of its
+ * weight-gradient half: out[3 * task + k]; needs GMP_STEP_TIMING=1 */
+int gmp_step_head_ms(float* out, int max_tasks);
 
 #ifdef __cplusplus
 }

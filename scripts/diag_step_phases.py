@@ -50,3 +50,7 @@ for rep in range(3):
     print("pipelined, last step (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f | sum %.0f" % (
         det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3,
         sum(det[i] for i in range(13)) * 1e3))
+    hd = (C.c_float * 24)()
+    L.check(L.lib().gmp_step_head_ms(hd, 8), "heads")
+    print("   heads, us after the forward [start, input half done, weight half done]: " +
+          "  ".join(f"{t}: {hd[3 * i] * 1e3:.0f} / {hd[3 * i + 1] * 1e3:.0f} / {hd[3 * i + 2] * 1e3:.0f}" for i, t in enumerate(eng.tasks)))
