@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void outer_relu_dropout_bwd_kernel(const float
 
 // weight / bias gradient of that layer: part[j][c] = sum over the j-th 256-row chunk of g[m] * X[m, c] (+ the chunk's sum of g in column F),
 // then the chunks in order: deterministic
-constexpr int WCS_ROWS = 256;
+constexpr int WCS_ROWS = 64;        // rows per partial block: 15 k rows -> 240 x (F / 64) blocks of 16 row steps (256-row chunks: 33 us of serial steps)
 __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ X, float* __restrict__ part,
                                                                       int64_t M, int F) {
     __shared__ float sh[4][64];
@@ -92,14 +92,18 @@ __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const floa
     if (rl == 0 && col < F) part[(int64_t)blockIdx.y * (F + 1) + col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
     if (threadIdx.x == 0 && blockIdx.x == 0) part[(int64_t)blockIdx.y * (F + 1) + F] = (shg[0] + shg[1]) + (shg[2] + shg[3]);
 }
+// one wave per output column: lanes stride the chunk partials, a butterfly adds them (fixed order: deterministic)
 __global__ __launch_bounds__(256) void weighted_colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out_w, float* __restrict__ out_b,
                                                                     int64_t nparts, int F) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int col = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x % 64;
     if (col > F) return;
     float s = 0.f;
-    for (int64_t q = 0; q < nparts; ++q) s += part[q * (F + 1) + col];
-    if (col < F) out_w[col] = s;
-    else if (out_b) out_b[0] = s;
+    for (int64_t q = lane; q < nparts; q += 64) s += part[q * (F + 1) + col];
+    s = gmp::wave_sum(s);
+    if (lane == 0) {
+        if (col < F) out_w[col] = s;
+        else if (out_b) out_b[0] = s;
+    }
 }
 
 int grid_for(int64_t n4) {
@@ -170,6 +174,6 @@ extern "C" int gmp_weighted_colsum(const float* g, const float* x, float* out_w,
     if (!ws || ws_bytes < gmp_weighted_colsum_workspace_bytes(rows, feat)) return gmp::fail(GMP_ERR_WORKSPACE, "weighted_colsum: workspace");
     const int64_t parts = (rows + WCS_ROWS - 1) / WCS_ROWS;
     hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3((unsigned)((feat + 63) / 64), (unsigned)parts), dim3(256), 0, st, g, x, (float*)ws, rows, feat);
-    hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((unsigned)((feat + 1 + 255) / 256)), dim3(256), 0, st, (const float*)ws, out_w, out_b, parts, feat);
+    hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((unsigned)((feat + 1 + 3) / 4)), dim3(256), 0, st, (const float*)ws, out_w, out_b, parts, feat);
     return gmp::check_launch("weighted_colsum kernels");
 }
