@@ -115,6 +115,17 @@ class StepInputs:
         return t
 
 
+def _merge_runs(ranges):
+    """[k0, k1) tensor-index ranges -> the fewest contiguous runs covering them (one PCGrad launch set per run)."""
+    out = []
+    for a, b in sorted(r for r in ranges if r[1] > r[0]):
+        if out and out[-1][1] == a:
+            out[-1][1] = b
+        else:
+            out.append([a, b])
+    return out
+
+
 class StepPlan:
     """Host-side description of one stacked step (pure index data)."""
     pass
@@ -1635,7 +1646,7 @@ class StepEngine:
             k_of = self._part_tensors
             sync.average_(self.lib, torch.cuda.current_stream(self.device), gate=(self.sync_flags.data_ptr(), self._epoch),
                           exchange=self.grad_sync is not None,
-                          after_message=lambda parts, st: [pcgrad(k_of[b][0], k_of[b][1], 1, st) for b in parts])
+                          after_message=lambda parts, st: [pcgrad(a, b, 1, st) for a, b in _merge_runs([k_of[q] for q in parts])])
             pcgrad(0, self.K, 2, self._st())
             return
         if self.grad_sync is not None:
