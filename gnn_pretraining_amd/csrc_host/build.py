@@ -15,7 +15,7 @@ def build(verbose: bool = True) -> str:
     src = os.path.join(here, "hostdraw.cpp")
     if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
         return out
-    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-DTORCH_EXTENSION_NAME=_hostdraw", "-DTORCH_API_INCLUDE_EXTENSION_H",
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-DTORCH_EXTENSION_NAME=_hostdraw", "-DTORCH_API_INCLUDE_EXTENSION_H",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", src, "-o", out,
            "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
     cmd += ["-I" + p for p in E.include_paths()]
