@@ -272,23 +272,32 @@ __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
 
 __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
     __shared__ double sh[TB];
+    __shared__ int shc[TB], shp[TB];
     double s = 0.0;
     for (int i = threadIdx.x; i < a.K * CH; i += TB) s += (double)a.partial[i];
+    // the conflict / projection counts ride the same tree (one thread walking the K slots one dependent load after the other was
+    // 8 of this launch's 12 us, on the serial tail of the step)
+    int c = 0, pr = 0;
+    for (int b = threadIdx.x; b < a.K; b += TB) {
+        c += a.block_metrics[2 * b];
+        pr += a.block_metrics[2 * b + 1];
+    }
     sh[threadIdx.x] = s;
+    shc[threadIdx.x] = c;
+    shp[threadIdx.x] = pr;
     __syncthreads();
     for (int d = TB / 2; d > 0; d >>= 1) {
-        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        if (threadIdx.x < d) {
+            sh[threadIdx.x] += sh[threadIdx.x + d];
+            shc[threadIdx.x] += shc[threadIdx.x + d];
+            shp[threadIdx.x] += shp[threadIdx.x + d];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         a.normsq[0] = (float)sh[0];
-        int c = 0, pr = 0;
-        for (int b = 0; b < a.K; ++b) {
-            c += a.block_metrics[2 * b];
-            pr += a.block_metrics[2 * b + 1];
-        }
-        a.metrics[0] = c;
-        a.metrics[1] = pr;
+        a.metrics[0] = shc[0];
+        a.metrics[1] = shp[0];
     }
 }
 
