@@ -38,6 +38,7 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
                                                         const float4* __restrict__ addend = nullptr) {
     // XCD-aware: hardware deals blocks round-robin over 8 XCDs; give XCD k the k-th
     // contiguous eighth of the chunk space (gridDim.x is a multiple of 8).
+    __builtin_amdgcn_s_setprio(3);
     const int per_xcd = gridDim.x / NUM_XCD;
     const int lb = (blockIdx.x % NUM_XCD) * per_xcd + blockIdx.x / NUM_XCD;
     const int lane = threadIdx.x % GMP_WAVE, wv = threadIdx.x / GMP_WAVE;

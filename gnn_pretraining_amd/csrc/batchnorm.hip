@@ -129,6 +129,7 @@ template <int RPT, int RL = SRL>
 __global__ __launch_bounds__(RL * SCQ) void bn_fwd_short_kernel(BnArgs a) {
     constexpr int SRL = RL;          // shadows the 32-lane default below
     __shared__ float4 sh[SRL][SCQ];
+    __builtin_amdgcn_s_setprio(3);
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
     const int c = blockIdx.y * SCOLS + cq * 4;
     const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
@@ -313,6 +314,7 @@ template <int RPT, int RL = SRL>
 __global__ __launch_bounds__(RL * SCQ) void bn_bwd_short_kernel(BnArgs a) {
     constexpr int SRL = RL;
     __shared__ float4 sh[SRL][SCQ];
+    __builtin_amdgcn_s_setprio(3);
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
     const int c = blockIdx.y * SCOLS + cq * 4;
     const int r0 = a.seg_ptr[s], r1 = a.seg_ptr[s + 1], n = r1 - r0;
