@@ -169,6 +169,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const GemmArgs g) {
     // two LDS stages: the tile of K-step k+1 is written while step k is multiplied -> one barrier per step
     __shared__ __attribute__((aligned(16))) float As[2][BK * LA::LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LB::LD];
+    __builtin_amdgcn_s_setprio(2);
 
     const int t = threadIdx.x, lane = t % 64, wv = t / 64;
     const int wm = wv / 2, wn = wv % 2, l31 = lane & 31, half = lane >> 5;
