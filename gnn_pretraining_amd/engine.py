@@ -1738,6 +1738,15 @@ class StepEngine:
         bufs += [b for n, b in self.model.named_buffers() if "running_" in n and not n.startswith("input_encoders.")]
         saved = [b.clone() for b in bufs]
         host_state = (self.step_count, self._bn_calls, list(self._bn_calls_dom), self._nprng, dict(self.host_ms))
+        # the link-prediction negatives draw from a stream of their own (neg_rng / its native twin): both passes must see the same one
+        neg_state = (self.neg_rng.getstate(), self._neg_native.getstate().clone() if self._neg_native is not None else None)
+
+        def rewind_negatives() -> None:
+            self.neg_rng.setstate(neg_state[0])
+            if self._neg_native is not None and neg_state[1] is not None:
+                self._neg_native.setstate(neg_state[1])
+            elif self._neg_native is not None:
+                self._neg_native = None                  # created during the first pass: the second re-creates it from neg_rng
         tasks = [t for t in self.tasks if t != "domain_adv"]
         self._chk(self.lib.gmp_gate_set_timeout(float(timeout_s)), "gate_set_timeout")
         outs, timed_out = [], False
@@ -1748,6 +1757,7 @@ class StepEngine:
                     b.copy_(s)
                 self.step_count = host_state[0]
                 self._nprng = None
+                rewind_negatives()
                 g = torch.Generator().manual_seed(12345)
                 for _ in range(steps):
                     self.step(inp, g, order=tasks)
@@ -1760,15 +1770,21 @@ class StepEngine:
             for b, s in zip(bufs, saved):
                 b.copy_(s)
             self.step_count, self._bn_calls, self._bn_calls_dom, self._nprng = host_state[0], host_state[1], host_state[2], host_state[3]
+            rewind_negatives()
             self.host_ms.update(host_state[4])
             self._chk(self.lib.gmp_gate_set_timeout(float(os.environ.get("GMP_GATE_TIMEOUT_S", "120"))), "gate_set_timeout")
         ok = (not timed_out) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+        if not ok and not timed_out:          # name what differed: a mismatch is a synchronisation bug, not a tuning matter
+            labels = ["parameters", "per-task gradients", "loss sums"] + [f"buffer {i}" for i in range(len(outs[0]) - 3)]
+            self.gates_mismatch = [(n, float((a.double() - b.double()).abs().max())) for n, a, b in zip(labels, outs[0], outs[1]) if not torch.equal(a, b)]
         if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
             t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
             tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
             ok = bool(t.item())
         self.use_gates = ok
         self.gates_verified = {"ok": ok, "timed_out": timed_out, "steps": steps}
+        if getattr(self, "gates_mismatch", None):
+            self.gates_verified["mismatch"] = self.gates_mismatch
         torch.cuda.synchronize(dev)
         return ok
 

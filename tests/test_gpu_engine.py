@@ -562,3 +562,26 @@ def test_device_rng_mode_draws_valid_artefacts_and_trains():
     eng.check_gates()
     assert len(seen) == 12 and len(set(seen)) > 6
     assert all(np.isfinite(v) for v in eng.losses().values())
+
+
+def test_verify_gates_compares_like_with_like_and_restores_the_engine():
+    """StepEngine.verify_gates (the start-up self-check a data-parallel run makes after the process group exists): its two passes --
+    gates, then events -- must start from the same state INCLUDING the link-prediction negatives' own random stream (graphs too large
+    for "every non-edge" draw from it), so on a healthy box the answer is True; and parameters, optimiser state, step count and both
+    random streams are as before the call: the next step equals the step of an engine that never ran the check."""
+    import random
+    big = lambda gen, doms: {d: S.domain_batch(gen, S.DOMAIN_SHAPES[d][0], 8, 60.0, 130.0) for d in doms}      # graphs that sample their negatives
+    _, hm, eng, host, inp, gen, tasks, _ = build("s4", 91, make_host=big, neg_rng=random.Random(5))
+    if not eng.use_gates:
+        pytest.skip("no hardware queue per stream on this box")
+    _, hm2, eng2, _, inp2, _, _, _ = build("s4", 91, make_host=big, neg_rng=random.Random(5))
+    eng.dropout_p = eng2.dropout_p = 0.2
+    assert eng.verify_gates(inp) is True, eng.gates_verified
+    assert eng.use_gates and eng.gates_verified["ok"] and not eng.gates_verified["timed_out"]
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    for _ in range(2):
+        eng.step(inp, g1, order=list(tasks))
+        eng2.step(inp2, g2, order=list(tasks))
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat, eng2.flat) and torch.equal(eng.task_grads, eng2.task_grads) and torch.equal(eng.loss_sums, eng2.loss_sums)
+    assert eng.sync_neg_rng().getstate() == eng2.sync_neg_rng().getstate()
