@@ -71,21 +71,27 @@ GRAPHS_PER_STEP = 32
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 # HBM bytes per launch of the aggregation kernel at exactly this rung, from separate rocprofv3 --pmc passes (FETCH_SIZE x 2: gfx950
 # reports half of wide coalesced reads, MI355X_MICROARCH.md section HBM; + WRITE_SIZE; x 1024).  PMC passes cannot run inside this
-# process, so the figure is a constant -- tied to the source it was measured on: `roofline.traffic` is reported only while
-# csrc/aggregate.hip still hashes to PMC_SOURCE_SHA16 (and the rung is PMC_SHAPE), null otherwise (re-measure: profiles/README.md).
+# process, so the figure is a constant -- tied to the source it was measured on: `roofline.traffic` is reported only while the
+# lines of csrc/aggregate.hip between its [pmc-stamp-begin] / [pmc-stamp-end] markers (the kernel the passes measured, and its
+# launcher) still hash to PMC_SOURCE_SHA16 and the rung is PMC_SHAPE; null otherwise (re-measure: profiles/README.md).
 PMC_SHAPE = (2146816, 8068480)
 PMC_TRAFFIC_BYTES = int((1229083.6 * 2 + 2146899.6) * 1024)     # profiles/r02b_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
 PMC_TRAFFIC_BYTES_BWD = int((2689371.2 * 2 + 2167702.9) * 1024) # same file, backward with the eps row products (1.16 x algorithmic)
-PMC_SOURCE_SHA16 = "238f502693b22f8b"                           # sha256(csrc/aggregate.hip)[:16] of the measured kernels
+PMC_SOURCE_SHA16 = "71aa7c7be9734a64"                           # sha256 of the marked region of the measured source, first 16 hex digits
+
+
+def pmc_source_sha16():
+    import hashlib
+    try:
+        txt = open(os.path.join(ROOT, "gnn_pretraining_amd", "csrc", "aggregate.hip"), encoding="utf-8").read()
+        region = txt[txt.index("// [pmc-stamp-begin]"):txt.index("// [pmc-stamp-end]")]
+    except (OSError, ValueError):
+        return None
+    return hashlib.sha256(region.encode()).hexdigest()[:16]
 
 
 def pmc_traffic(shape, backward: bool = False):
-    import hashlib
-    try:
-        sha = hashlib.sha256(open(os.path.join(ROOT, "gnn_pretraining_amd", "csrc", "aggregate.hip"), "rb").read()).hexdigest()[:16]
-    except OSError:
-        return None
-    return (PMC_TRAFFIC_BYTES_BWD if backward else PMC_TRAFFIC_BYTES) if (shape == PMC_SHAPE and sha == PMC_SOURCE_SHA16) else None
+    return (PMC_TRAFFIC_BYTES_BWD if backward else PMC_TRAFFIC_BYTES) if (shape == PMC_SHAPE and pmc_source_sha16() == PMC_SOURCE_SHA16) else None
 
 
 ROOFLINE_BWD = None
@@ -189,7 +195,7 @@ def aggregation_roofline(device, graphs: int = 65536, distinct: int = 1024, iter
                                                "gradient, N >= 65536)", "rows": N, "edges": E, "bytes_per_launch": bytes_b,
                     "avg_launch_ms": round(ms_b, 4), "launches": iters, "frac_of_copy_ceiling": round(ach_b / 6290.0, 4)}
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic((N, E)), "traffic_source": f"rocprofv3 --pmc passes on aggregate.hip sha256 {PMC_SOURCE_SHA16}", "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic((N, E)), "traffic_source": f"rocprofv3 --pmc passes on the marked kernel region of aggregate.hip, sha256 {PMC_SOURCE_SHA16}", "kernel": "gin_aggregate_ldstile_kernel (gmp_gin_aggregate_fwd, N >= 65536)",
             "rows": N, "edges": E, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 4), "launches": iters,
             # for orientation only (frac above is against the 8 TB/s spec): the part's measured float4 copy rate, MI355X_MICROARCH.md
             "measured_copy_ceiling": 6290.0, "frac_of_copy_ceiling": round(achieved / 6290.0, 4)}

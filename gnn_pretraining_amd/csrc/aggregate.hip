@@ -193,6 +193,7 @@ __global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* 
 // hold of a tile laid out thread-linear (thread i <-> row i / 64 = wave + 16 k), so the dotx tile never goes through LDS: each
 // thread loads its own nine float4 of it when the tile is entered -- in flight beside the next tile's prefetch while the first
 // rows are reduced -- and multiplies them with the row it is reducing anyway.  One extra KiB per row read, nothing re-read.
+// [pmc-stamp-begin] bench.py stamps roofline.traffic with the hash of the lines between these two markers (the kernel the PMC passes measured and its launcher)
 template <int SB, int TILE, int CCAP, bool NT_STORE, bool DOT = false>
 __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
                                                                    const int* __restrict__ col, const float* __restrict__ eps,
@@ -412,6 +413,7 @@ int launch_ldstile144(const float* x, const int* rowptr, const int* col, const f
                        (const float4*)dotx, rowdot);
     return gmp::check_launch("gin_aggregate_ldstile_kernel");
 }
+// [pmc-stamp-end]
 
 // sum of n floats in a fixed order: `nb` block partials (grid-stride by block, tree inside), then reduce_partials_kernel over them
 __global__ __launch_bounds__(256) void block_partials_kernel(const float* __restrict__ p, int64_t n, float* __restrict__ part) {
