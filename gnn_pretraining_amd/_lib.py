@@ -110,6 +110,11 @@ _SIGS: Dict[str, tuple] = {
     "gmp_outer_relu_dropout_bwd": (C.c_int, [p, p, p, p, i64, i32, C.c_float, C.c_uint64, C.c_uint32, p]),
     "gmp_weighted_colsum_workspace_bytes": (sz, [i64, i32]),
     "gmp_weighted_colsum": (C.c_int, [p, p, p, p, i64, i32, p, sz, p]),
+    "gmp_lp_pair_rowdot_fwd": (C.c_int, [p, p, p, p, p, i64, i32, C.c_float, C.c_uint64, C.c_uint32, p]),
+    "gmp_lp_pair_sigmoid_bce_fwd_bwd": (C.c_int, [p, p, p, i64, p, p, p, p, p, sz, p]),
+    "gmp_lp_pair_outer_bwd": (C.c_int, [p, p, p, p, p, i64, i32, C.c_float, C.c_uint64, C.c_uint32, p]),
+    "gmp_lp_pair_colsum_workspace_bytes": (sz, [i64, i32]),
+    "gmp_lp_pair_weighted_colsum": (C.c_int, [p, p, p, p, p, i64, i32, C.c_float, C.c_uint64, C.c_uint32, p, sz, p]),
     "gmp_loss_workspace_bytes": (sz, [i64]),
     "gmp_mse_sum_fwd": (C.c_int, [p, p, i64, p, p, sz, p]),
     "gmp_mse_sum_bwd": (C.c_int, [p, p, p, p, i64, p]),

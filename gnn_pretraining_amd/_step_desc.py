@@ -21,7 +21,7 @@ class TaskDesc(C.Structure):
                 ("ntx_n", i32 * MAXD), ("ntx_ws", p * MAXD), ("ntx_ws_bytes", sz * MAXD), ("ntx_sums", p), ("temperature", f32),
                 ("pool_ptr", p), ("pool_gid", p), ("pool_B", i32), ("pool_r0", i32), ("pool_M", i32),
                 ("pool_mean", p), ("pool_max", p), ("g_mean", p), ("g_max", p), ("labels", p),
-                ("lp_K", i64), ("lp_edges", p), ("lp_labels", p),
+                ("lp_K", i64), ("lp_edges", p), ("lp_labels", p), ("lp_pos", p),
                 ("lp_feat", p), ("lp_y1", p), ("lp_d1", p), ("lp_y2", p), ("lp_p", p), ("lp_gp", p), ("lp_gy2", p), ("lp_gy1", p),
                 ("lp_gfeat", p), ("lp_ghs", p), ("lp_ghd", p),
                 ("lp_off_w0", i64), ("lp_off_b0", i64), ("lp_off_w3", i64), ("lp_off_b3", i64),

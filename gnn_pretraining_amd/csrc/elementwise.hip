@@ -106,6 +106,113 @@ __global__ __launch_bounds__(256) void weighted_colsum_final_kernel(const float*
     }
 }
 
+// ---- the same layer over MERGED link-prediction rows: one row per unordered pair through the 768 -> 256 layer and its ReLU (identical
+// for (i, j) and (j, i): the features of heads.py:57-61 are symmetric), but the reference's Dropout(0.2) (heads.py:44-52) draws a mask for
+// every ORDERED row of its list (tasks.py:111-120), so a merged row that stands for two ordered rows has two masks, two scores, two
+// BCE terms.  pos[m] = ordered position of the row's first occurrence, pos[M + m] = of its second (-1: none); a mask is keyed by
+// (seed, site, ordered position * F/4 + column quad) -- exactly the key the unmerged path (dropout_rowdot_kernel over the ordered
+// list) uses, so per ordered row the two paths draw the same mask and compute the same score, bit for bit.
+// y[m] = score of the first occurrence, y[M + m] = of the second (copy of the first when p = 0; unused when there is none).
+__global__ __launch_bounds__(256) void lp_pair_rowdot_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ b,
+                                                             const int32_t* __restrict__ pos, float* __restrict__ y, int64_t M, int F4, float p,
+                                                             uint64_t seed, uint32_t sid) {
+    const int lane = threadIdx.x % 64;
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const float bias = b ? b[0] : 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + threadIdx.x / 64; m < M; m += (int64_t)gridDim.x * 4) {
+        const int64_t pa = pos[m], pb = pos[M + m];
+        float sa = 0.f, sb = 0.f;
+        for (int c = lane; c < F4; c += 64) {
+            const float4 v = x[m * F4 + c], ww = w[c];
+            if (p > 0.f) {
+                const float4 k = gmp::dropout_scale4(seed, sid, (uint64_t)(pa * F4 + c), p, inv);
+                sa += ((v.x * k.x) * ww.x + (v.y * k.y) * ww.y) + ((v.z * k.z) * ww.z + (v.w * k.w) * ww.w);
+                if (pb >= 0) {
+                    const float4 q = gmp::dropout_scale4(seed, sid, (uint64_t)(pb * F4 + c), p, inv);
+                    sb += ((v.x * q.x) * ww.x + (v.y * q.y) * ww.y) + ((v.z * q.z) * ww.z + (v.w * q.w) * ww.w);
+                }
+            } else {
+                sa += (v.x * ww.x + v.y * ww.y) + (v.z * ww.z + v.w * ww.w);
+            }
+        }
+        sa = gmp::wave_sum(sa);
+        sb = p > 0.f ? gmp::wave_sum(sb) : sa;
+        if (lane == 0) {
+            y[m] = sa + bias;
+            y[M + m] = sb + bias;
+        }
+    }
+}
+
+// out[m, c] = (act[m, c] > 0) * w[c] * (g[m] * mask_a + g[M + m] * mask_b): the two ordered rows' input gradients added (they meet in the
+// 768 -> 256 layer's weight and input gradients anyway); g[M + m] is zero where the row has no second occurrence
+__global__ __launch_bounds__(256) void lp_pair_outer_bwd_kernel(const float* __restrict__ g, const float4* __restrict__ w, const float4* __restrict__ act,
+                                                                const int32_t* __restrict__ pos, float4* __restrict__ out, int64_t M, int F4, float p,
+                                                                uint64_t seed, uint32_t sid) {
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int64_t n4 = M * F4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / F4;
+        const int c = (int)(i - m * F4);
+        const float ga = g[m], gb = g[M + m];
+        const float4 ww = w[c], a = act[i];
+        float4 k = make_float4(ga + gb, ga + gb, ga + gb, ga + gb);
+        if (p > 0.f) {
+            const int64_t pa = pos[m], pb = pos[M + m];
+            const float4 ka = gmp::dropout_scale4(seed, sid, (uint64_t)(pa * F4 + c), p, inv);
+            k = make_float4(ga * ka.x, ga * ka.y, ga * ka.z, ga * ka.w);
+            if (pb >= 0) {
+                const float4 kb = gmp::dropout_scale4(seed, sid, (uint64_t)(pb * F4 + c), p, inv);
+                k = make_float4(k.x + gb * kb.x, k.y + gb * kb.y, k.z + gb * kb.z, k.w + gb * kb.w);
+            }
+        }
+        out[i] = make_float4(a.x > 0.f ? ww.x * k.x : 0.f, a.y > 0.f ? ww.y * k.y : 0.f, a.z > 0.f ? ww.z * k.z : 0.f, a.w > 0.f ? ww.w * k.w : 0.f);
+    }
+}
+
+// weight / bias gradient of the layer over merged rows: part[j][c] = sum over the j-th chunk of rows of act[m, c] * (g[m] * mask_a + g[M + m] * mask_b)
+// (+ the chunk's sum of g[m] + g[M + m] in column F); the dropped activations are rebuilt from the masks, never stored.  One wave per row,
+// lane = column quad (F <= 256), four rows of a chunk in flight per block; weighted_colsum_final_kernel adds the chunks in order.
+constexpr int LPW_ROWS = 32;
+__global__ __launch_bounds__(256) void lp_pair_colsum_partial_kernel(const float* __restrict__ g, const float4* __restrict__ act, const int32_t* __restrict__ pos,
+                                                                     float* __restrict__ part, int64_t M, int F4, float p, uint64_t seed, uint32_t sid) {
+    __shared__ float4 sh[4][64];
+    __shared__ float shg[4];
+    const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int64_t r0 = (int64_t)blockIdx.x * LPW_ROWS, r1 = r0 + LPW_ROWS < M ? r0 + LPW_ROWS : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sg = 0.f;
+    for (int64_t m = r0 + wv; m < r1; m += 4) {
+        const float ga = g[m], gb = g[M + m];
+        sg += ga + gb;
+        if (lane < F4) {
+            const float4 a = act[m * F4 + lane];
+            float4 k = make_float4(ga + gb, ga + gb, ga + gb, ga + gb);
+            if (p > 0.f) {
+                const int64_t pa = pos[m], pb = pos[M + m];
+                const float4 ka = gmp::dropout_scale4(seed, sid, (uint64_t)(pa * F4 + lane), p, inv);
+                k = make_float4(ga * ka.x, ga * ka.y, ga * ka.z, ga * ka.w);
+                if (pb >= 0) {
+                    const float4 kb = gmp::dropout_scale4(seed, sid, (uint64_t)(pb * F4 + lane), p, inv);
+                    k = make_float4(k.x + gb * kb.x, k.y + gb * kb.y, k.z + gb * kb.z, k.w + gb * kb.w);
+                }
+            }
+            s = make_float4(s.x + a.x * k.x, s.y + a.y * k.y, s.z + a.z * k.z, s.w + a.w * k.w);
+        }
+    }
+    sh[wv][lane] = s;
+    if (lane == 0) shg[wv] = sg;
+    __syncthreads();
+    const int F = 4 * F4;
+    if (wv == 0 && lane < F4) {
+        const float4 a = sh[0][lane], b = sh[1][lane], c = sh[2][lane], d = sh[3][lane];
+        float* o = part + (int64_t)blockIdx.x * (F + 1) + 4 * lane;
+        o[0] = (a.x + b.x) + (c.x + d.x); o[1] = (a.y + b.y) + (c.y + d.y); o[2] = (a.z + b.z) + (c.z + d.z); o[3] = (a.w + b.w) + (c.w + d.w);
+    }
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * (F + 1) + F] = (shg[0] + shg[1]) + (shg[2] + shg[3]);
+}
+
 int grid_for(int64_t n4) {
     int64_t b = (n4 + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -176,4 +283,56 @@ extern "C" int gmp_weighted_colsum(const float* g, const float* x, float* out_w,
     hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3((unsigned)((feat + 63) / 64), (unsigned)parts), dim3(256), 0, st, g, x, (float*)ws, rows, feat);
     hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((unsigned)((feat + 1 + 3) / 4)), dim3(256), 0, st, (const float*)ws, out_w, out_b, parts, feat);
     return gmp::check_launch("weighted_colsum kernels");
+}
+
+// ---- merged link-prediction rows, one dropout mask per ORDERED row (kernels above) ------------------------------------------------------
+static int lp_pair_args(const char* what, int64_t rows, int feat, float p, const int32_t* pos) {
+    if (rows < 0 || feat <= 0 || feat % 4 || feat > 256 || p < 0.f || p >= 1.f) return gmp::fail(GMP_ERR_ARG, "%s: rows=%lld feat=%d p=%f", what, (long long)rows, feat, p);
+    if (rows > 0 && !pos) return gmp::fail(GMP_ERR_ARG, "%s: null positions", what);
+    return GMP_OK;
+}
+
+extern "C" int gmp_lp_pair_rowdot_fwd(const float* x, const float* w, const float* bias, const int32_t* pos, float* y2, int64_t rows, int feat, float p,
+                                      uint64_t seed, uint32_t stream_id, gmp_stream_t stream) {
+    if (int rc = lp_pair_args("lp_pair_rowdot_fwd", rows, feat, p, pos)) return rc;
+    if (rows == 0) return GMP_OK;
+    if (!x || !w || !y2) return gmp::fail(GMP_ERR_ARG, "lp_pair_rowdot_fwd: null pointer");
+    const int64_t blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(lp_pair_rowdot_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)w, bias, pos, y2, rows, feat / 4, p, seed, stream_id);
+    return gmp::check_launch("lp_pair_rowdot_kernel");
+}
+
+extern "C" int gmp_lp_pair_outer_bwd(const float* g_y2, const float* w, const float* act, const int32_t* pos, float* out, int64_t rows, int feat, float p,
+                                     uint64_t seed, uint32_t stream_id, gmp_stream_t stream) {
+    if (int rc = lp_pair_args("lp_pair_outer_bwd", rows, feat, p, pos)) return rc;
+    if (rows == 0) return GMP_OK;
+    if (!g_y2 || !w || !act || !out) return gmp::fail(GMP_ERR_ARG, "lp_pair_outer_bwd: null pointer");
+    hipLaunchKernelGGL(lp_pair_outer_bwd_kernel, dim3(grid_for(rows * (feat / 4))), dim3(256), 0, (hipStream_t)stream, g_y2, (const float4*)w,
+                       (const float4*)act, pos, (float4*)out, rows, feat / 4, p, seed, stream_id);
+    return gmp::check_launch("lp_pair_outer_bwd_kernel");
+}
+
+extern "C" size_t gmp_lp_pair_colsum_workspace_bytes(int64_t rows, int feat) {
+    if (rows <= 0 || feat <= 0) return 0;
+    return (size_t)((rows + LPW_ROWS - 1) / LPW_ROWS) * (size_t)(feat + 1) * sizeof(float);
+}
+
+extern "C" int gmp_lp_pair_weighted_colsum(const float* g_y2, const float* act, const int32_t* pos, float* out_w, float* out_b, int64_t rows, int feat,
+                                           float p, uint64_t seed, uint32_t stream_id, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    if (int rc = lp_pair_args("lp_pair_weighted_colsum", rows, feat, p, pos)) return rc;
+    if (!out_w) return gmp::fail(GMP_ERR_ARG, "lp_pair_weighted_colsum: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        (void)hipMemsetAsync(out_w, 0, (size_t)feat * sizeof(float), st);
+        if (out_b) (void)hipMemsetAsync(out_b, 0, sizeof(float), st);
+        return GMP_OK;
+    }
+    if (!g_y2 || !act) return gmp::fail(GMP_ERR_ARG, "lp_pair_weighted_colsum: null pointer");
+    if (!ws || ws_bytes < gmp_lp_pair_colsum_workspace_bytes(rows, feat)) return gmp::fail(GMP_ERR_WORKSPACE, "lp_pair_weighted_colsum: workspace");
+    const int64_t parts = (rows + LPW_ROWS - 1) / LPW_ROWS;
+    hipLaunchKernelGGL(lp_pair_colsum_partial_kernel, dim3((unsigned)parts), dim3(256), 0, st, g_y2, (const float4*)act, pos, (float*)ws, rows, feat / 4, p, seed,
+                       stream_id);
+    hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((unsigned)((feat + 1 + 3) / 4)), dim3(256), 0, st, (const float*)ws, out_w, out_b, parts, feat);
+    return gmp::check_launch("lp_pair_weighted_colsum kernels");
 }

@@ -92,6 +92,28 @@ __global__ __launch_bounds__(T) void sigmoid_bce_kernel(const float* __restrict_
     block_sum_store(s, part);
 }
 
+// The same pass over MERGED link-prediction rows (elementwise.hip lp_pair_*): x = [2, M] scores (first / second ordered occurrence of every
+// row), sign[m] > 0 for a positive pair, pos[M + m] < 0 where a row has no second occurrence (its entry adds nothing: loss 0, gradient 0).
+// Every ordered row of the reference's list (tasks.py:111-120) gets its own term, as in the unmerged pass.
+__global__ __launch_bounds__(T) void sigmoid_bce_pair_kernel(const float* __restrict__ x, const float* __restrict__ sign, const int32_t* __restrict__ pos,
+                                                             const float* __restrict__ gs, float* __restrict__ p_out, float* __restrict__ gx, int64_t M,
+                                                             float* part) {
+    const float g = gs[0];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < 2 * M; i += (int64_t)gridDim.x * T) {
+        const int64_t m = i < M ? i : i - M;
+        const bool live = i < M || pos[i] >= 0;
+        const float p = 1.f / (1.f + expf(-x[i]));
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(log1pf(-p), -100.f);
+        const float yi = sign[m] > 0.f ? 1.f : 0.f;
+        const float gp = g * (p - yi) / fmaxf((1.f - p) * p, 1e-12f);
+        if (live) s -= yi * lp + (1.f - yi) * lq;
+        gx[i] = live ? gp * p * (1.f - p) : 0.f;
+        if (p_out) p_out[i] = live ? p : 0.f;
+    }
+    block_sum_store(s, part);
+}
+
 // one wave per row: loss_m = logsumexp(logits[m,:]) - logits[m,target]; probs optional output
 __global__ __launch_bounds__(T) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t M, int C,
                                                     float* __restrict__ rowloss, float* __restrict__ gl, const float* __restrict__ gs) {
@@ -201,6 +223,17 @@ extern "C" int gmp_sigmoid_bce_sum_fwd_bwd(const float* x, const float* labels, 
 extern "C" int gmp_sigmoid_bce_signed_sum_fwd_bwd(const float* x, const float* signed_weight, int64_t n, const float* g_scale, float* loss,
                                                  float* p_out, float* g_x, void* ws, size_t ws_bytes, gmp_stream_t stream) {
     return sigmoid_bce_launch(true, x, signed_weight, n, g_scale, loss, p_out, g_x, ws, ws_bytes, stream);
+}
+extern "C" int gmp_lp_pair_sigmoid_bce_fwd_bwd(const float* y2, const float* sign, const int32_t* pos, int64_t rows, const float* g_scale, float* loss,
+                                               float* p_out, float* g_y2, void* ws, size_t ws_bytes, gmp_stream_t stream) {
+    const int64_t n = rows;
+    GMP_CHECK_N("lp_pair_sigmoid_bce_fwd_bwd")
+    if (!loss || !g_scale || !ws || ws_bytes < MAX_PARTS * sizeof(float) || (n > 0 && (!y2 || !sign || !pos || !g_y2)))
+        return gmp::fail(GMP_ERR_ARG, "lp_pair_sigmoid_bce_fwd_bwd: bad argument");
+    const int parts = parts_for(2 * n);
+    hipLaunchKernelGGL(sigmoid_bce_pair_kernel, dim3(parts), dim3(T), 0, st, y2, sign, pos, g_scale, p_out, g_y2, n, (float*)ws);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(T), 0, st, (const float*)ws, parts, loss);
+    return gmp::check_launch("lp_pair_sigmoid_bce kernels");
 }
 extern "C" int gmp_cross_entropy_sum_fwd(const float* logits, const int64_t* target, int64_t M, int C, float* loss, void* ws,
                                          size_t ws_bytes, gmp_stream_t stream) {

@@ -191,10 +191,17 @@ int task_head_inputs(const gmp_step_desc& d, int ti, gmp_stream_t st, float** d1
             // pushed through the dropout and the ReLU (gmp_dropout_rowdot_fwd / gmp_outer_relu_dropout_bwd: no N = 1 GEMM launches)
             const float pdrop = d.training && d.dropout_p > 0.f ? d.dropout_p : 0.f;
             float* ld1 = pdrop > 0.f ? t.lp_d1 : t.lp_y1;
-            GMP_TRY(gmp_dropout_rowdot_fwd(t.lp_y1, w3, b3, t.lp_d1, t.lp_y2, K, H, pdrop, d.seed, t.lp_site, st));
-            GMP_TRY(gmp_sigmoid_bce_signed_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
-            *d1_out = ld1;
-            GMP_TRY(gmp_outer_relu_dropout_bwd(t.lp_gy2, w3, t.lp_y1, t.lp_gy1, K, H, pdrop, d.seed, t.lp_site, st));
+            if (t.lp_pos) {       // merged rows (one per unordered pair): a dropout mask, a score and a BCE term per ORDERED row (gnnmp.h gmp_lp_pair_*)
+                GMP_TRY(gmp_lp_pair_rowdot_fwd(t.lp_y1, w3, b3, t.lp_pos, t.lp_y2, K, H, pdrop, d.seed, t.lp_site, st));
+                GMP_TRY(gmp_lp_pair_sigmoid_bce_fwd_bwd(t.lp_y2, t.lp_labels, t.lp_pos, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
+                *d1_out = t.lp_y1;
+                GMP_TRY(gmp_lp_pair_outer_bwd(t.lp_gy2, w3, t.lp_y1, t.lp_pos, t.lp_gy1, K, H, pdrop, d.seed, t.lp_site, st));
+            } else {
+                GMP_TRY(gmp_dropout_rowdot_fwd(t.lp_y1, w3, b3, t.lp_d1, t.lp_y2, K, H, pdrop, d.seed, t.lp_site, st));
+                GMP_TRY(gmp_sigmoid_bce_signed_sum_fwd_bwd(t.lp_y2, t.lp_labels, K, t.g_scale, t.loss_sum, t.lp_p, t.lp_gy2, t.loss_ws, t.loss_ws_bytes, st));
+                *d1_out = ld1;
+                GMP_TRY(gmp_outer_relu_dropout_bwd(t.lp_gy2, w3, t.lp_y1, t.lp_gy1, K, H, pdrop, d.seed, t.lp_site, st));
+            }
             GMP_TRY(gemm(GMP_GEMM_NN, t.lp_gy1, w0, nullptr, t.lp_gfeat, K, 3 * H, H, H, 3 * H, 3 * H, false, st));
             GMP_TRY(gmp_lp_edge_features_bwd(t.lp_gfeat, hL, t.lp_edges, t.lp_ghs, t.lp_ghd, N, K, H, st));
             float* g_rows = gH + (int64_t)H * t.row0;
@@ -295,6 +302,9 @@ int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1)
             GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, t.lp_gy1, t.lp_feat, nullptr, tg, 1, one, nullptr, nullptr, cw0, tg, cb0, H, 3 * H, 0, H, 3 * H, 3 * H,
                                          1.f, 0, 0, t.gemm_ws, t.gemm_ws_bytes, st));
             // dW3 [1, 256] and db3: a weighted column sum (the grouped GEMM path took 54 us for these 257 numbers)
+            if (t.lp_pos)
+                return gmp_lp_pair_weighted_colsum(t.lp_gy2, t.lp_y1, t.lp_pos, tg + t.lp_tg_w3, tg + t.lp_tg_b3, K, H,
+                                                   d.training && d.dropout_p > 0.f ? d.dropout_p : 0.f, d.seed, t.lp_site, t.gemm_ws, t.gemm_ws_bytes, st);
             return gmp_weighted_colsum(t.lp_gy2, d1, tg + t.lp_tg_w3, tg + t.lp_tg_b3, K, H, t.gemm_ws, t.gemm_ws_bytes, st);
         }
         case GMP_TASK_DA: {

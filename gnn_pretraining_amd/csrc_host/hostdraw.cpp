@@ -398,19 +398,27 @@ pybind11::list draw_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
 // collation and batched_negative_sampling both are); ptr: the batch's node offsets.  Returns pairs [2, K'] (min, max) + offset --
 // all positives, then all negatives, each in first-occurrence order -- and signed multiplicities (+count positives, -count
 // negatives).  Pairs never cross graphs, so the counting table is one graph's n x n (a few KB: it stays in L1).
-// shared by merge_mirrored_pairs and plan_step: appends the merged pairs of ONE domain batch to (oa, ob, ow); returns an error text or null
+// shared by merge_mirrored_pairs and plan_step: appends the merged pairs of ONE domain batch to (oa, ob, ow, opa, opb); returns an error text or null.
+// A merged row stands for ONE or TWO ordered rows of the reference's list (heads.py:44-52 draws an independent dropout mask for every
+// ordered row, so the scorer's tail needs to know which they were): opa[row] = position of the first occurrence in the reference's ordered
+// list of the step, opb[row] = of the second (-1: none); positions count from ord_base (this domain's first positive; its negatives follow
+// its positives, tasks.py:111-113).  ow = sign * (1 or 2).  A third occurrence of a pair (a duplicated edge) starts a row of its own.
 static const char* merge_pairs_core(const int64_t* ps, const int64_t* pd, int64_t Ep, const int64_t* ns, const int64_t* nd, int64_t En,
-                                    const int64_t* p, int64_t G, int64_t offset, std::vector<int64_t>& oa, std::vector<int64_t>& ob,
-                                    std::vector<float>& ow, std::vector<uint16_t>& count) {
+                                    const int64_t* p, int64_t G, int64_t offset, int64_t ord_base, std::vector<int64_t>& oa, std::vector<int64_t>& ob,
+                                    std::vector<float>& ow, std::vector<int32_t>& opa, std::vector<int32_t>& opb, std::vector<int32_t>& slot) {
     size_t out = oa.size();
-    oa.resize(out + (size_t)(Ep + En)); ob.resize(out + (size_t)(Ep + En)); ow.resize(out + (size_t)(Ep + En));
+    const size_t cap = out + (size_t)(Ep + En) + 1;           // (+1: the branch-free loop below writes one row past the last emitted one)
+    oa.resize(cap); ob.resize(cap); ow.resize(cap); opa.resize(cap); opb.resize(cap);
     int64_t *wa = oa.data(), *wb = ob.data();
     float* ww = ow.data();
+    int32_t *pa = opa.data(), *pb = opb.data();
     const char* err = nullptr;
+    if (ord_base + Ep + En > INT32_MAX) err = "hostdraw: ordered pair list too long for int32 positions";
     for (int grp = 0; grp < 2 && !err; ++grp) {
         const int64_t E = grp ? En : Ep;
         const int64_t *s = grp ? ns : ps, *d = grp ? nd : pd;
         const float sign = grp ? -1.f : 1.f;
+        const int64_t ord0 = ord_base + (grp ? Ep : 0);
         int64_t e = 0;
         for (int64_t gi = 0; gi < G && e < E && !err; ++gi) {
             const int64_t lo = p[gi], hi = p[gi + 1], n = hi - lo;
@@ -418,57 +426,67 @@ static const char* merge_pairs_core(const int64_t* ps, const int64_t* pd, int64_
             while (e1 < E && s[e1] >= lo && s[e1] < hi) ++e1;             // this graph's run of pairs
             if (e1 == e) continue;
             if (n > 4096) { err = "hostdraw: graph too large for the pair table"; break; }
-            if ((int64_t)count.size() < n * n) count.assign((size_t)(n * n), 0);      // (every touched entry is reset below: all zero between graphs)
+            if ((int64_t)slot.size() < n * n) slot.assign((size_t)(n * n), 0);      // (every touched entry is reset below: all zero between graphs)
             for (int64_t k = e; k < e1; ++k) {
-                const int64_t x = s[k] - lo, y = d[k] - lo;
+                const int64_t y = d[k] - lo;
                 if (y < 0 || y >= n) { err = "hostdraw: pair crosses graphs"; break; }
-                uint16_t& c = count[(size_t)((x < y ? x : y) * n + (x < y ? y : x))];
-                if (c == 65535) { err = "hostdraw: pair multiplicity overflow"; break; }
-                ++c;
             }
             if (err) break;
+            // slot[a * n + b] = 1 + the row that holds ONE occurrence of the pair so far (0: none, or its row is full).  Branch-free: half of
+            // these tests go either way with no pattern (fresh pairs every step), a mispredict each
             for (int64_t k = e; k < e1; ++k) {
                 const int64_t x = s[k] - lo, y = d[k] - lo, a = x < y ? x : y, b = x < y ? y : x;
-                uint16_t& c = count[(size_t)(a * n + b)];
-                // branch-free: half of these tests go either way with no pattern (fresh pairs every step), a mispredict each
-                wa[out] = a + lo + offset; wb[out] = b + lo + offset; ww[out] = sign * (float)c;
-                out += c != 0;
-                c = 0;
+                int32_t& sl = slot[(size_t)(a * n + b)];
+                const bool fresh = sl == 0;
+                const size_t row = fresh ? out : (size_t)(sl - 1);
+                const int32_t ord = (int32_t)(ord0 + k);
+                wa[row] = a + lo + offset; wb[row] = b + lo + offset;      // (the same values when the row exists already)
+                pa[row] = fresh ? ord : pa[row];
+                pb[row] = fresh ? -1 : ord;
+                ww[row] = fresh ? sign : 2.f * sign;
+                sl = fresh ? (int32_t)(out + 1) : 0;
+                out += fresh;
+            }
+            for (int64_t k = e; k < e1; ++k) {
+                const int64_t x = s[k] - lo, y = d[k] - lo;
+                slot[(size_t)((x < y ? x : y) * n + (x < y ? y : x))] = 0;
             }
             e = e1;
         }
         if (!err && e != E) err = "hostdraw: pairs are not grouped by graph in batch order";
     }
-    if (err) std::fill(count.begin(), count.end(), 0);            // (a failed call may have left counts behind)
-    oa.resize(out); ob.resize(out); ow.resize(out);
+    if (err) std::fill(slot.begin(), slot.end(), 0);            // (a failed call may have left entries behind)
+    oa.resize(out); ob.resize(out); ow.resize(out); opa.resize(out); opb.resize(out);
     return err;
 }
 
-std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at::Tensor ptr, int64_t offset) {
+std::vector<at::Tensor> merge_mirrored_pairs(at::Tensor pos, at::Tensor neg, at::Tensor ptr, int64_t offset, int64_t ord_base) {
     for (const at::Tensor* t : {&pos, &neg})
         TORCH_CHECK(t->dim() == 2 && t->size(0) == 2 && t->scalar_type() == at::kLong && t->is_contiguous() && t->device().is_cpu(),
                     "hostdraw: pairs must be contiguous CPU int64 [2, E]");
     TORCH_CHECK(ptr.dim() == 1 && ptr.numel() >= 1 && ptr.scalar_type() == at::kLong && ptr.is_contiguous(), "hostdraw: ptr");
     static thread_local std::vector<int64_t> va, vb;          // scratch that keeps its capacity across calls
     static thread_local std::vector<float> vw;
-    static thread_local std::vector<uint16_t> count;
-    va.clear(); vb.clear(); vw.clear();
+    static thread_local std::vector<int32_t> vpa, vpb, slot;
+    va.clear(); vb.clear(); vw.clear(); vpa.clear(); vpb.clear();
     const char* err;
     {
         pybind11::gil_scoped_release nogil;
         const int64_t Ep = pos.size(1), En = neg.size(1);
         err = merge_pairs_core(pos.data_ptr<int64_t>(), pos.data_ptr<int64_t>() + Ep, Ep, neg.data_ptr<int64_t>(), neg.data_ptr<int64_t>() + En, En,
-                               ptr.data_ptr<int64_t>(), ptr.numel() - 1, offset, va, vb, vw, count);
+                               ptr.data_ptr<int64_t>(), ptr.numel() - 1, offset, ord_base, va, vb, vw, vpa, vpb, slot);
     }
     TORCH_CHECK(!err, err);
     const int64_t out = (int64_t)va.size();
-    at::Tensor pairs = at::empty({2, out}, at::kLong), w = at::empty({out}, at::kFloat);
+    at::Tensor pairs = at::empty({2, out}, at::kLong), w = at::empty({out}, at::kFloat), ord = at::empty({2, out}, at::kInt);
     if (out) {
         std::memcpy(pairs.data_ptr<int64_t>(), va.data(), (size_t)out * sizeof(int64_t));
         std::memcpy(pairs.data_ptr<int64_t>() + out, vb.data(), (size_t)out * sizeof(int64_t));
         std::memcpy(w.data_ptr<float>(), vw.data(), (size_t)out * sizeof(float));
+        std::memcpy(ord.data_ptr<int32_t>(), vpa.data(), (size_t)out * sizeof(int32_t));
+        std::memcpy(ord.data_ptr<int32_t>() + out, vpb.data(), (size_t)out * sizeof(int32_t));
     }
-    return {pairs, w};
+    return {pairs, w, ord};
 }
 
 // engine.StepEngine.plan in one call with the GIL released: the stacked layout of a step -- segments (one per reference forward()
@@ -581,6 +599,7 @@ pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
                     sizes[t] = rows.back() * hidden;
                 } else if (kind == 1) {
                     std::vector<int64_t> pa, pb, seg_eptr{0};
+                    std::vector<int32_t> ord_a, ord_b;               // merged rows: the one or two ordered positions each stands for
                     int64_t ordered = 0;
                     for (size_t d = 0; d < D && !err; ++d) {
                         const at::Tensor& ptr = std::get<0>(doms[d]);
@@ -594,14 +613,16 @@ pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
                             if (x.dim() != 2 || x.size(0) != 2) { err = "plan_step: negatives must be [2, K]"; break; }
                             En = x.size(1); ns = x.data_ptr<int64_t>(); nd = ns + En;
                         }
+                        const int64_t ord_base = ordered;
                         ordered += Ep + En;
                         const int64_t before = (int64_t)pa.size();
                         if (!lp_merge) {
                             for (int64_t e = 0; e < Ep; ++e) { pa.push_back(ps[e] + r0s[d]); pb.push_back(pd[e] + r0s[d]); lp_labels.push_back(1.f); }
                             for (int64_t e = 0; e < En; ++e) { pa.push_back(ns[e] + r0s[d]); pb.push_back(nd[e] + r0s[d]); lp_labels.push_back(-1.f); }
                         } else {
-                            static thread_local std::vector<uint16_t> count;
-                            err = merge_pairs_core(ps, pd, Ep, ns, nd, En, ptr.data_ptr<int64_t>(), ptr.numel() - 1, r0s[d], pa, pb, lp_labels, count);
+                            static thread_local std::vector<int32_t> slot;
+                            err = merge_pairs_core(ps, pd, Ep, ns, nd, En, ptr.data_ptr<int64_t>(), ptr.numel() - 1, r0s[d], ord_base, pa, pb, lp_labels,
+                                                   ord_a, ord_b, slot);
                             if (err) break;
                         }
                         seg_eptr.push_back(seg_eptr.back() + (int64_t)pa.size() - before);
@@ -614,6 +635,11 @@ pybind11::dict plan_step(std::vector<int> kinds, std::vector<std::tuple<at::Tens
                     auto& lsp = out.add(out.a32, "lp_seg_ptr");
                     lsp = r0s; lsp.push_back(seg_ptr.back());
                     out.add(out.a32, "lp_seg_eptr") = seg_eptr;
+                    if (lp_merge) {
+                        auto& lpos = out.add(out.a32, "lp_pos");
+                        lpos.assign(ord_a.begin(), ord_a.end());
+                        lpos.insert(lpos.end(), ord_b.begin(), ord_b.end());
+                    }
                     sc["lp_S"] = (int64_t)D; sc["lp_rows_end"] = seg_ptr.back();
                     int64_t mr = 0, me = 0;
                     for (size_t d = 0; d < D; ++d) { mr = std::max(mr, lsp[d + 1] - lsp[d]); me = std::max(me, seg_eptr[d + 1] - seg_eptr[d]); }

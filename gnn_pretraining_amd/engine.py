@@ -183,7 +183,7 @@ class _Views(dict):
         super().__init__()
         self._cat, self._lay = cat, {n: (o, k) for n, o, k in lay}
 
-    _SHAPES = {"lp_edges": (2, -1), "edge_index": (2, -1), "tiles": (-1, 2)}
+    _SHAPES = {"lp_edges": (2, -1), "edge_index": (2, -1), "tiles": (-1, 2), "lp_pos": (2, -1)}
 
     def __missing__(self, name):
         o, k = self._lay[name]
@@ -236,23 +236,42 @@ def L_view_sizes(ptr_host):
 _HOSTDRAW, _HOSTDRAW_TRIED = None, False
 
 
-def merge_mirrored_pairs(b: Batch, neg: np.ndarray, offset: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Unordered pairs [2, K'] (+offset) and signed multiplicities (+w positive, -w negative) of one domain batch's scored pairs (its
-    edges, then the drawn negatives): the LP scorer's features (heads.py:57-61) are symmetric in (src, dst), so (i, j) and (j, i) need
-    one row, not two.  Native (csrc_host/hostdraw.cpp) when built, numpy otherwise; both keep first-occurrence order, positives first."""
+def merge_mirrored_pairs(b: Batch, neg: np.ndarray, offset: int, ord_base: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Unordered pairs [2, K'] (+offset), signed multiplicities (+w positive, -w negative; w = 1 or 2) and ordered positions [2, K'] int32 of
+    one domain batch's scored pairs (its edges, then the drawn negatives): the LP scorer's features (heads.py:57-61) are symmetric in
+    (src, dst), so (i, j) and (j, i) need one row through the 768 -> 256 layer, not two.  The reference drops every ORDERED row with a mask of
+    its own (heads.py:44-52), so each merged row remembers the one or two ordered rows it stands for: ord[0] = position of the first
+    occurrence in the reference's list (counted from ord_base: this domain's positives, then its negatives), ord[1] = of the second (-1: none).
+    A third occurrence of a pair (a duplicated edge) starts a row of its own.  Native (csrc_host/hostdraw.cpp) when built, numpy otherwise;
+    both keep first-occurrence order, positives first."""
     H = hostdraw()
     if H is not None and hasattr(H, "merge_mirrored_pairs"):
         ptr, _, ei = _host_tensors(b)
-        pairs, w = H.merge_mirrored_pairs(ei, torch.from_numpy(np.ascontiguousarray(neg)), ptr, int(offset))
-        return pairs.numpy(), w.numpy()
-    out_p, out_w, n = [], [], max(b.num_nodes, 1)
+        pairs, w, ord_ = H.merge_mirrored_pairs(ei, torch.from_numpy(np.ascontiguousarray(neg)), ptr, int(offset), int(ord_base))
+        return pairs.numpy(), w.numpy(), ord_.numpy()
+    out_p, out_w, out_o, n = [], [], [], max(b.num_nodes, 1)
+    base = int(ord_base)
     for sign, e in ((1.0, b.edge_index.numpy()), (-1.0, neg)):
         lo, hi = np.minimum(e[0], e[1]), np.maximum(e[0], e[1])
-        _, first, cnt = np.unique(lo * n + hi, return_index=True, return_counts=True)
-        order = np.argsort(first, kind="stable")
-        out_p.append(np.stack([lo[first[order]], hi[first[order]]]) + offset)
-        out_w.append((sign * cnt[order]).astype(np.float32))
-    return np.concatenate(out_p, axis=1), np.concatenate(out_w)
+        key = lo * n + hi
+        order = np.argsort(key, kind="stable")
+        sk = key[order]
+        ar = np.arange(len(sk))
+        start = np.ones(len(sk), dtype=bool)
+        start[1:] = sk[1:] != sk[:-1]
+        rank = ar - np.maximum.accumulate(np.where(start, ar, 0))           # occurrence number of every entry among its equals
+        lead = np.flatnonzero(rank % 2 == 0)                                    # sorted positions that open a row
+        nxt = np.minimum(lead + 1, len(sk) - 1)
+        has2 = (lead + 1 < len(sk)) & (sk[nxt] == sk[lead]) if len(sk) else np.zeros(0, dtype=bool)
+        first = order[lead]
+        second = np.where(has2, order[nxt], -1)
+        emit = np.argsort(first, kind="stable")                                 # rows in first-occurrence order
+        first, second, has2 = first[emit], second[emit], has2[emit]
+        out_p.append(np.stack([lo[first], hi[first]]) + offset)
+        out_w.append((sign * (1 + has2)).astype(np.float32))
+        out_o.append(np.stack([first + base, np.where(has2, second + base, -1)]).astype(np.int32))
+        base += e.shape[1]
+    return np.concatenate(out_p, axis=1), np.concatenate(out_w), np.concatenate(out_o, axis=1)
 
 
 def hostdraw():
@@ -503,12 +522,13 @@ class StepEngine:
             "da_g1": (1024, DA_HIDDEN), "da_gin": (1024, H),
             "gp_in": (1024, H), "gp_y1": (1024, 2 * H), "gp_d1": (1024, 2 * H), "gp_y2": (1024, 16), "gp_g2": (1024, 16), "gp_g1": (1024, 2 * H), "gp_gin": (1024, H),
         }.items()}
-        self.lp_y2, self.lp_p, self.lp_gp, self.lp_gy2 = f(self.KMAX), f(self.KMAX), f(self.KMAX), f(self.KMAX)      # (lp_lab: upload set below)
+        # (lp_lab: upload set below; merged rows keep two scores each -- one per ordered row of the reference's list)
+        self.lp_y2, self.lp_p, self.lp_gp, self.lp_gy2 = f(2 * self.KMAX), f(2 * self.KMAX), f(self.KMAX), f(2 * self.KMAX)
         self.gp_y2 = f(1024, GRAPH_PROPERTY_DIM)
         self.gp_g2 = f(1024, GRAPH_PROPERTY_DIM)
         self.ntx_ws = [torch.empty(self.lib.gmp_nt_xent_grouped_workspace_bytes(self.D, 512, 128), dtype=torch.uint8, device=dev) for _ in range(2 * self.D)]
         # packed per-step index uploads (pinned staging)
-        self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536, 4 * self.max_edges + 8 * R
+        self.i32_cap, self.i64_cap = 4 * R + 8 * self.S_MAX + 65536 + 2 * self.max_edges, 4 * self.max_edges + 8 * R
         # The host runs several steps ahead of the GPU (nothing in a step syncs), so the pinned staging buffers
         # form a ring: a slot is refilled only after the copy that last read it has completed (event per slot).
         self.STAGES = 4
@@ -968,14 +988,15 @@ class StepEngine:
                     p.nfm_rows = rows
                     sizes[t] = rows[-1] * H
                 elif t == "link_pred":
-                    eds, labs, npos, ordered = [], [], [], 0
+                    eds, labs, npos, ordered, ords = [], [], [], 0, []
                     for d, r0 in zip(D, r0s):
                         hb = inp.host[d]
                         neg = np.asarray(art[t][d], dtype=np.int64)
+                        ord_base = ordered
                         ordered += hb.edge_index.size(1) + neg.shape[1]
                         if self.lp_merge:
-                            pairs, w = merge_mirrored_pairs(hb, neg, r0)
-                            eds.append(pairs); labs.append(w)
+                            pairs, w, od = merge_mirrored_pairs(hb, neg, r0, ord_base)
+                            eds.append(pairs); labs.append(w); ords.append(od)
                             npos.append((pairs.shape[1], 0))
                         else:
                             eds += [hb.edge_index.numpy() + r0, neg + r0]
@@ -991,6 +1012,8 @@ class StepEngine:
                     # block diagonal by domain: the decoder CSR is built one workgroup per (domain, orientation)
                     a32["lp_seg_ptr"] = np.asarray(r0s + [seg_ptr[-1]])
                     a32["lp_seg_eptr"] = np.concatenate([[0], np.cumsum([a + b for a, b in npos])])
+                    if self.lp_merge:           # [2, K']: the ordered row(s) of the reference's list every merged row stands for
+                        a32["lp_pos"] = np.concatenate(ords, axis=1) if ords else np.zeros((2, 0), dtype=np.int32)
                     p.lp_S, p.lp_rows_end = len(r0s), seg_ptr[-1]
                     p.lp_max_rows = int(np.diff(a32["lp_seg_ptr"]).max())
                     p.lp_max_edges = int(np.diff(a32["lp_seg_eptr"]).max())
@@ -1441,19 +1464,32 @@ class StepEngine:
             pdrop = self.dropout_p if (self.model.training and self.dropout_p > 0) else 0.0
             dseed = (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1)
             d1 = hd["lp_d1"] if pdrop > 0 else hd["lp_y1"]
-            self._chk(lib.gmp_dropout_rowdot_fwd(hd["lp_y1"].data_ptr(), w3, b3, hd["lp_d1"].data_ptr(), self.lp_y2.data_ptr(), K, H, pdrop, dseed,
-                                                 100 + ti, st), "lp rowdot")
-            self._chk(lib.gmp_sigmoid_bce_signed_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
-                                                      self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "sigmoid+bce")
+            pos = p.d32.get("lp_pos")            # merged rows: the ordered row(s) each stands for (a dropout mask per ordered row)
+            if pos is not None:
+                self._chk(lib.gmp_lp_pair_rowdot_fwd(hd["lp_y1"].data_ptr(), w3, b3, pos, self.lp_y2.data_ptr(), K, H, pdrop, dseed, 100 + ti, st), "lp pair rowdot")
+                self._chk(lib.gmp_lp_pair_sigmoid_bce_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), pos, K, gs, ls, self.lp_p.data_ptr(),
+                                                              self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "pair sigmoid+bce")
+                self._chk(lib.gmp_lp_pair_outer_bwd(self.lp_gy2.data_ptr(), w3, hd["lp_y1"].data_ptr(), pos, hd["lp_gy1"].data_ptr(), K, H, pdrop, dseed,
+                                                    100 + ti, st), "lp pair outer")
+            else:
+                self._chk(lib.gmp_dropout_rowdot_fwd(hd["lp_y1"].data_ptr(), w3, b3, hd["lp_d1"].data_ptr(), self.lp_y2.data_ptr(), K, H, pdrop, dseed,
+                                                     100 + ti, st), "lp rowdot")
+                self._chk(lib.gmp_sigmoid_bce_signed_sum_fwd_bwd(self.lp_y2.data_ptr(), self.lp_lab.data_ptr(), K, gs, ls, self.lp_p.data_ptr(),
+                                                          self.lp_gy2.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "sigmoid+bce")
+                self._chk(lib.gmp_outer_relu_dropout_bwd(self.lp_gy2.data_ptr(), w3, hd["lp_y1"].data_ptr(), hd["lp_gy1"].data_ptr(), K, H, pdrop, dseed,
+                                                         100 + ti, st), "lp outer")
             one = [0, K]
-            self._chk(lib.gmp_outer_relu_dropout_bwd(self.lp_gy2.data_ptr(), w3, hd["lp_y1"].data_ptr(), hd["lp_gy1"].data_ptr(), K, H, pdrop, dseed,
-                                                     100 + ti, st), "lp outer")
             # dW0 with db0 riding along (column sums of the A tile already in LDS)
             self._gemm_g(TN, hd["lp_gy1"].data_ptr(), hd["lp_feat"].data_ptr(), None, tg, one, None, None,
                          [TG(ti, "heads.link_pred.predictor.mlp.0.weight")], tg, [TG(ti, "heads.link_pred.predictor.mlp.0.bias")], H, 3 * H, 0, H, 3 * H, 3 * H)
-            self._chk(lib.gmp_weighted_colsum(self.lp_gy2.data_ptr(), d1.data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.weight"),
-                                              tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.bias"), K, H, self._cur_gemm_ws.data_ptr(),
-                                              self._cur_gemm_ws.numel(), st), "lp dW3")
+            if pos is not None:
+                self._chk(lib.gmp_lp_pair_weighted_colsum(self.lp_gy2.data_ptr(), hd["lp_y1"].data_ptr(), pos, tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.weight"),
+                                                          tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.bias"), K, H, pdrop, dseed, 100 + ti,
+                                                          self._cur_gemm_ws.data_ptr(), self._cur_gemm_ws.numel(), st), "lp pair dW3")
+            else:
+                self._chk(lib.gmp_weighted_colsum(self.lp_gy2.data_ptr(), d1.data_ptr(), tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.weight"),
+                                                  tg + 4 * TG(ti, "heads.link_pred.predictor.mlp.3.bias"), K, H, self._cur_gemm_ws.data_ptr(),
+                                                  self._cur_gemm_ws.numel(), st), "lp dW3")
             self._gemm(NN, hd["lp_gy1"].data_ptr(), w0, None, hd["lp_gfeat"].data_ptr(), K, 3 * H, H, H, 3 * H, 3 * H)
             self._chk(lib.gmp_lp_edge_features_bwd(hd["lp_gfeat"].data_ptr(), hL.data_ptr(), p.d64["lp_edges"], hd["lp_ghs"].data_ptr(),
                                                    hd["lp_ghd"].data_ptr(), N, K, H, st), "lp feat bwd")
@@ -1969,6 +2005,7 @@ class StepEngine:
                 td.da_labels, td.da_lambda, td.da_dropout = p.d64["da_labels"], float(self.grl_lambda), float(self.da_dropout)
             if t == "link_pred":
                 td.lp_K, td.lp_edges = p.lp_K, p.d64["lp_edges"]
+                td.lp_pos = p.d32.get("lp_pos")
                 if self._lp_segmented(p):
                     d.lp_seg_ptr, d.lp_seg_eptr, d.lp_S = p.d32["lp_seg_ptr"], p.d32["lp_seg_eptr"], p.lp_S
                     d.lp_max_seg_rows, d.lp_max_seg_edges, d.lp_rows_end = p.lp_max_rows, p.lp_max_edges, p.lp_rows_end

@@ -638,3 +638,24 @@ def weighted_colsum(g: Tensor, x: Tensor):
     ws = _ws(l.gmp_weighted_colsum_workspace_bytes(rows, F), x.device)
     L.check(l.gmp_weighted_colsum(_ptr(g), _ptr(x), _ptr(ow), _ptr(ob), rows, F, _ptr(ws), ws.numel(), _stream(x)), "gmp_weighted_colsum")
     return ow, ob
+
+
+def lp_pair_head(y1: Tensor, w: Tensor, bias: Tensor, pos: Tensor, sign: Tensor, g_scale: Tensor, p: float, seed: int, stream_id: int):
+    """The link-prediction scorer's tail over MERGED rows (one per unordered pair), one dropout mask / score / BCE term per ORDERED row of the
+    reference's list (heads.py:44-52, tasks.py:111-120; gnnmp.h gmp_lp_pair_*).  y1 [K, F] = ReLU output of the 768 -> 256 layer, pos [2, K] int32
+    ordered positions (second -1 = none), sign [K] (> 0: positive pair).  Returns (y2 [2, K], loss_sum [1], g_y2 [2, K], g_y1 [K, F], g_w [F], g_b [1])."""
+    _need(y1, torch.float32, "y1", 2)
+    _need(pos, torch.int32, "pos", 2)
+    K, F = y1.shape
+    l, dev, st, sd = L.lib(), y1.device, _stream(y1), seed & (2 ** 64 - 1)
+    y2, g_y2, prob = (torch.empty(2, K, dtype=torch.float32, device=dev) for _ in range(3))
+    loss, g_w, g_b, g_y1 = torch.zeros(1, device=dev), torch.empty(F, device=dev), torch.empty(1, device=dev), torch.empty_like(y1)
+    lws = _ws(l.gmp_loss_workspace_bytes(2 * K), dev)
+    L.check(l.gmp_lp_pair_rowdot_fwd(_ptr(y1), _ptr(w), _ptr(bias), _ptr(pos), _ptr(y2), K, F, float(p), sd, stream_id, st), "gmp_lp_pair_rowdot_fwd")
+    L.check(l.gmp_lp_pair_sigmoid_bce_fwd_bwd(_ptr(y2), _ptr(sign), _ptr(pos), K, _ptr(g_scale), _ptr(loss), _ptr(prob), _ptr(g_y2), _ptr(lws), lws.numel(), st),
+            "gmp_lp_pair_sigmoid_bce_fwd_bwd")
+    L.check(l.gmp_lp_pair_outer_bwd(_ptr(g_y2), _ptr(w), _ptr(y1), _ptr(pos), _ptr(g_y1), K, F, float(p), sd, stream_id, st), "gmp_lp_pair_outer_bwd")
+    ws = _ws(l.gmp_lp_pair_colsum_workspace_bytes(K, F), dev).clone()
+    L.check(l.gmp_lp_pair_weighted_colsum(_ptr(g_y2), _ptr(y1), _ptr(pos), _ptr(g_w), _ptr(g_b), K, F, float(p), sd, stream_id, _ptr(ws), ws.numel(), st),
+            "gmp_lp_pair_weighted_colsum")
+    return y2, loss, g_y2, g_y1, g_w, g_b

@@ -303,6 +303,30 @@ size_t gmp_weighted_colsum_workspace_bytes(int64_t rows, int feat);
 int gmp_weighted_colsum(const float* g, const float* x, float* out_w, float* out_b, int64_t rows, int feat, void* workspace,
                         size_t workspace_bytes, gmp_stream_t stream);
 
+/* The same layer over MERGED link-prediction rows.  The scorer's features [hs + hd, hs * hd, |hs - hd|] (src/models/heads.py:57-61) are
+ * symmetric in (src, dst), so the engine sends one row per unordered pair through Linear(768, 256) + ReLU; but the reference scores an
+ * ORDERED list (src/pretrain/tasks.py:111-120: positives in both directions, then the negatives) and its Dropout(0.2) (heads.py:44-52) draws
+ * an independent mask for every row of that list.  A merged row therefore carries the one or two ordered rows it stands for:
+ * pos[m] = position of its first occurrence in the reference's list, pos[rows + m] = of its second, or -1.  Masks are keyed by
+ * (seed, stream_id, ordered position * feat / 4 + column quad) -- the key gmp_dropout_rowdot_fwd uses when it is run over the ordered list --
+ * so every ordered row gets the mask, the score and the loss term the unmerged path gives it (scores bit for bit).
+ *   gmp_lp_pair_rowdot_fwd:       y2[m] / y2[rows + m] = <dropout_{first / second}(x[m, :]), w> + bias[0]   (second = first when p == 0)
+ *   gmp_lp_pair_sigmoid_bce_fwd_bwd (losses): loss = sum over ordered rows of BCE(sigmoid(y2), sign[m] > 0) with torch's -100 clamp,
+ *                                 g_y2 = d (g_scale * loss) / d y2 (zero where there is no second occurrence), p_out nullable [2 rows]
+ *   gmp_lp_pair_outer_bwd:        out[m, c] = (act[m, c] > 0) * w[c] * (g_y2[m] * mask_first + g_y2[rows + m] * mask_second)
+ *   gmp_lp_pair_weighted_colsum:  out_w[c] = sum_m act[m, c] * (g_y2[m] * mask_first + g_y2[rows + m] * mask_second),
+ *                                 out_b[0] = sum_m g_y2[m] + g_y2[rows + m]  (nullable); two ordered stages, deterministic
+ * feat % 4 == 0, feat <= 256.  workspace >= gmp_lp_pair_colsum_workspace_bytes(rows, feat). */
+int gmp_lp_pair_rowdot_fwd(const float* x, const float* w, const float* bias, const int32_t* pos, float* y2, int64_t rows, int feat, float p,
+                           uint64_t seed, uint32_t stream_id, gmp_stream_t stream);
+int gmp_lp_pair_sigmoid_bce_fwd_bwd(const float* y2, const float* sign, const int32_t* pos, int64_t rows, const float* g_scale, float* loss,
+                                    float* p_out, float* g_y2, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+int gmp_lp_pair_outer_bwd(const float* g_y2, const float* w, const float* act, const int32_t* pos, float* out, int64_t rows, int feat, float p,
+                          uint64_t seed, uint32_t stream_id, gmp_stream_t stream);
+size_t gmp_lp_pair_colsum_workspace_bytes(int64_t rows, int feat);
+int gmp_lp_pair_weighted_colsum(const float* g_y2, const float* act, const int32_t* pos, float* out_w, float* out_b, int64_t rows, int feat,
+                                float p, uint64_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes, gmp_stream_t stream);
+
 /* Grouped form: the per-domain problems of one contrastive task (tasks.py:192-213, 265-287 loop over domains) in 7 launches
  * instead of 7 per domain; forward and backward in one call.  Group g's 2*n_host[g] rows [z1; z2] start at row
  * row_off_host[g] of z [*, dim] and its gradient goes to the same rows of g_z; loss_sums[g] (nullable) receives the group's

@@ -57,6 +57,10 @@ typedef struct {
     const float* labels;          /* GP: [B, 12] */
     /* link prediction */
     int64_t lp_K; const int64_t* lp_edges; const float* lp_labels;
+    /* lp_pos: NULL = lp_edges is the reference's ordered list (lp_labels +1 / -1).  Otherwise lp_edges holds one row per unordered pair and
+       lp_pos [2, lp_K] names the one or two ordered rows each stands for (gnnmp.h gmp_lp_pair_*: a dropout mask, a score and a loss term per
+       ordered row); lp_y2 / lp_p / lp_gy2 then hold 2 lp_K floats and lp_d1 is unused. */
+    const int32_t* lp_pos;
     float *lp_feat, *lp_y1, *lp_d1, *lp_y2, *lp_p, *lp_gp, *lp_gy2, *lp_gy1, *lp_gfeat, *lp_ghs, *lp_ghd;
     /* offsets of a head shared by all domains: the LP scorer, and the domain classifier of GMP_TASK_DA */
     int64_t lp_off_w0, lp_off_b0, lp_off_w3, lp_off_b3, lp_tg_w0, lp_tg_b0, lp_tg_w3, lp_tg_b3;

@@ -585,3 +585,34 @@ def test_verify_gates_compares_like_with_like_and_restores_the_engine():
     torch.cuda.synchronize()
     assert torch.equal(eng.flat, eng2.flat) and torch.equal(eng.task_grads, eng2.task_grads) and torch.equal(eng.loss_sums, eng2.loss_sums)
     assert eng.sync_neg_rng().getstate() == eng2.sync_neg_rng().getstate()
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("scheme,seed", [("s4", 311), ("b3", 312)])
+def test_merged_link_prediction_rows_drop_every_ordered_row_independently(scheme, seed, native):
+    """Dropout ON (p = 0.2, the reference's heads.py:44-52): the default engine path scores each unordered pair once through the 768 -> 256
+    layer, but every ORDERED row of the reference's list (tasks.py:111-120) keeps its own dropout mask, score and BCE term.  Given masks keyed
+    by ordered position, the merged path must equal the GMP_LP_MERGE=0 path (which scores the ordered list row by row): the task's loss, its
+    gradient into every backbone / encoder parameter (i.e. g_h) and the head's own gradients, to 1e-6 relative."""
+    outs = []
+    for merge in (True, False):
+        om, hm, eng, host, inp, gen, tasks, domains = build(scheme, seed, native=native)
+        eng.lp_merge = merge
+        eng.dropout_p, eng.da_dropout = 0.2, 0.5
+        art = eng.draw(inp, gen)
+        eng.step(inp, gen, art=art, order=[t for t in tasks if t != "domain_adv"], apply_update=False)
+        ti = tasks.index("link_pred")
+        plan = eng.last_plan
+        assert ("lp_pos" in plan.a32) == merge
+        outs.append((eng.loss_sums[ti].item() / plan.sizes["link_pred"], eng.task_grads[ti].clone().cpu(), plan.lp_K, plan.sizes["link_pred"],
+                     {n: (eng.off[n], eng.numel[n]) for n in eng.names}))
+    (lm, gm, Km, nm, offs), (lu, gu, Ku, nu, _) = outs
+    assert nm == nu == Ku and Km < Ku                                  # the same ordered count; roughly half the rows through the GEMMs
+    assert abs(lm - lu) <= 1e-6 * abs(lu), (lm, lu)
+    gmax = gu.abs().max().item()
+    for n, (o, k) in offs.items():
+        a, b = gm[o:o + k].double(), gu[o:o + k].double()
+        if b.abs().max().item() == 0 and a.abs().max().item() == 0:
+            continue
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-3 * gmax)
+        assert err <= 1e-6, (n, err)

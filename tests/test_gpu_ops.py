@@ -541,3 +541,54 @@ def test_linear_to_one_column_kernels(rows, p):
     ow_ref, ob_ref = g.double() @ d_ref.double(), g.double().sum()
     assert (ow.double() - ow_ref).abs().max().item() <= 1e-5 * max(ow_ref.abs().max().item(), 1.0)
     assert abs(ob.item() - ob_ref.item()) <= 1e-5 * max(abs(ob_ref.item()), g.abs().sum().item() * 1e-2, 1.0)
+
+
+@pytest.mark.parametrize("K", [0, 1, 300, 15431])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_merged_pair_rows_keep_a_dropout_mask_per_ordered_row(K, p):
+    """gmp_lp_pair_* (one row per unordered pair, heads.py:57-61 being symmetric) against the UNMERGED kernels run over the reference's ordered
+    list (tasks.py:111-120) with the same (seed, site): every ordered row must get the mask it would get there (heads.py:44-52 drops every row
+    independently) -- scores bit for bit, loss / input gradient / weight gradient to 1e-6 (sums in another order)."""
+    from gnn_pretraining_amd import _lib as L
+    gen = torch.Generator().manual_seed(K + 3)
+    F = 256
+    two = torch.rand(K, generator=gen) < 0.7                                   # rows that stand for two ordered rows
+    n_ord = K + int(two.sum())
+    perm = torch.randperm(n_ord, generator=gen)                                # their positions in the ordered list, scattered
+    pos = torch.full((2, K), -1, dtype=torch.int32)
+    pos[0] = perm[:K].to(torch.int32)
+    pos[1, two] = perm[K:].to(torch.int32)
+    sign = torch.where(torch.rand(K, generator=gen) < 0.5, 1.0, -1.0) * (1.0 + two.float())
+    y1 = torch.relu(torch.randn(K, F, generator=gen))
+    w, b = torch.randn(F, generator=gen) * 0.1, torch.randn(1, generator=gen)
+    gs = torch.tensor([1.0 / max(n_ord, 1)])
+    y2, loss, g_y2, g_y1, g_w, g_b = ops.lp_pair_head(y1.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV), sign.to(DEV), gs.to(DEV), p, 4242, 101)
+    if K == 0:
+        assert loss.item() == 0 and g_w.abs().max().item() == 0 and g_b.item() == 0
+        return
+    # the ordered list, scored by the unmerged kernels
+    row_of = torch.empty(n_ord, dtype=torch.long)
+    row_of[pos[0].long()] = torch.arange(K)
+    row_of[pos[1, two].long()] = torch.arange(K)[two]
+    y1o = y1[row_of].contiguous().to(DEV)
+    lab = (sign[row_of] > 0).float().to(DEV)
+    d, yo = ops.dropout_rowdot_fwd(y1o, w.to(DEV), b.to(DEV), p, 4242, 101)
+    l = L.lib()
+    loss_o, g_yo, prob = torch.zeros(1, device=DEV), torch.empty(n_ord, device=DEV), torch.empty(n_ord, device=DEV)
+    lws = ops._ws(l.gmp_loss_workspace_bytes(n_ord), DEV)
+    L.check(l.gmp_sigmoid_bce_sum_fwd_bwd(ops._ptr(yo), ops._ptr(lab), n_ord, ops._ptr(gs.to(DEV)), ops._ptr(loss_o), ops._ptr(prob), ops._ptr(g_yo),
+                                          ops._ptr(lws), lws.numel(), ops._stream(yo)), "bce")
+    g_y1o = ops.outer_relu_dropout_bwd(g_yo, w.to(DEV), y1o, p, 4242, 101)
+    g_wo, g_bo = ops.weighted_colsum(g_yo, d)
+    yo, g_yo, g_y1o = yo.cpu(), g_yo.cpu(), g_y1o.cpu()
+    y2, g_y2 = y2.cpu(), g_y2.cpu()
+    assert torch.equal(y2[0], yo[pos[0].long()]) and torch.equal(y2[1][two], yo[pos[1, two].long()])          # scores: bit for bit
+    assert torch.equal(g_y2[0], g_yo[pos[0].long()]) and torch.equal(g_y2[1][two], g_yo[pos[1, two].long()])
+    assert (g_y2[1][~two] == 0).all()
+    if p > 0 and two.any():                                                                                   # the two masks of a row do differ
+        assert (y2[0][two] != y2[1][two]).any()
+    rel = lambda a, b: (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+    assert rel(loss.cpu(), loss_o.cpu()) <= 1e-6
+    want_g_y1 = torch.zeros(K, F, dtype=torch.float64).index_add_(0, row_of, g_y1o.double())                  # both ordered rows meet in the merged one
+    assert rel(g_y1.cpu(), want_g_y1) <= 1e-6
+    assert rel(g_w.cpu(), g_wo.cpu()) <= 2e-6 and abs(g_b.item() - g_bo.item()) <= 2e-6 * max(abs(g_bo.item()), g_yo.abs().sum().item() * 1e-2)

@@ -114,32 +114,45 @@ def test_native_negative_sampler_replays_pythons_random(seed):
 
 def test_merged_pairs_hold_the_ordered_list_as_a_multiset(monkeypatch):
     """engine.merge_mirrored_pairs: every ordered pair of the reference's list (positives, then negatives) stands in the merged list
-    as its (min, max) pair with the right sign, multiplicities add up to the ordered counts, and the native and numpy versions give
-    the same arrays (a directed edge, a duplicate and a self loop included)."""
+    as its (min, max) pair with the right sign, multiplicities add up to the ordered counts, every ordered position is named by exactly one
+    merged row (a row stands for one or two ordered rows: each keeps a dropout mask of its own, heads.py:44-52), and the native and numpy
+    versions give the same arrays (a directed edge, a self loop, a duplicate and a triplicate included)."""
     import random
     from gnn_pretraining_amd.engine import merge_mirrored_pairs
     cases = [(b, sample_negative_edges(b, random.Random(2)).numpy()) for b in _batches() if b.num_graphs]
     odd = Batch.from_data_list([Data(torch.zeros(4, 4), torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 2, 3, 3]]), torch.zeros(1, dtype=torch.long), torch.zeros(12)),
-                                Data(torch.zeros(3, 4), torch.tensor([[0, 0], [1, 1]]), torch.zeros(1, dtype=torch.long), torch.zeros(12))])
-    cases.append((odd, np.array([[0, 3, 0, 4, 6], [3, 0, 2, 6, 4]])))              # a directed edge, a self loop, a duplicate edge
+                                Data(torch.zeros(3, 4), torch.tensor([[0, 0, 1, 2, 1], [1, 1, 0, 1, 2]]), torch.zeros(1, dtype=torch.long), torch.zeros(12))])
+    cases.append((odd, np.array([[0, 3, 0, 4, 6], [3, 0, 2, 6, 4]])))              # a directed edge, a self loop, a duplicate, a triplicate
     for b, neg in cases:
         pos = b.edge_index
-        pairs, w = merge_mirrored_pairs(b, neg, 100)
+        pairs, w, od = merge_mirrored_pairs(b, neg, 100, 7)
         with monkeypatch.context() as m:
             m.setattr("gnn_pretraining_amd.engine._HOSTDRAW", None)
             m.setattr("gnn_pretraining_amd.engine._HOSTDRAW_TRIED", True)
-            pairs_np, w_np = merge_mirrored_pairs(b, neg, 100)
-        assert np.array_equal(pairs, pairs_np) and np.array_equal(w, w_np)
-        assert (pairs[0] <= pairs[1]).all() and pairs.dtype == np.int64 and w.dtype == np.float32
+            pairs_np, w_np, od_np = merge_mirrored_pairs(b, neg, 100, 7)
+        assert np.array_equal(pairs, pairs_np) and np.array_equal(w, w_np) and np.array_equal(od, od_np)
+        assert (pairs[0] <= pairs[1]).all() and pairs.dtype == np.int64 and w.dtype == np.float32 and od.dtype == np.int32 and od.shape == pairs.shape
         npos = int((w > 0).sum())
         assert (w[:npos] > 0).all() and (w[npos:] < 0).all()                         # positives first
+        assert np.array_equal(np.abs(w), 1.0 + (od[1] >= 0))                         # |w| = how many ordered rows the merged row stands for
+        ordered = np.concatenate([pos.numpy(), neg], axis=1)
+        named = np.concatenate([od[0], od[1][od[1] >= 0]]) - 7
+        assert sorted(named.tolist()) == list(range(ordered.shape[1]))             # every ordered row exactly once
+        for r in range(pairs.shape[1]):                                             # ... and it is that row's pair
+            for o in od[:, r]:
+                if o >= 0:
+                    i, j = ordered[:, o - 7]
+                    assert (min(i, j) + 100, max(i, j) + 100) == (pairs[0, r], pairs[1, r])
+        assert (np.diff(od[0]) > 0).all() and (od[1][od[1] >= 0] > od[0][od[1] >= 0]).all()      # first-occurrence order
         for sign, e, seg, ws in ((1, pos.numpy(), pairs[:, :npos], w[:npos]), (-1, neg, pairs[:, npos:], w[npos:])):
             keys = [(int(min(a, b)) + 100, int(max(a, b)) + 100) for a, b in e.T]
             want = {}
             for k in keys:
                 want[k] = want.get(k, 0) + 1
-            got = {(int(a), int(b)): int(sign * x) for a, b, x in zip(seg[0], seg[1], ws)}
-            assert got == want and len(got) == seg.shape[1]
+            got = {}
+            for a, b, x in zip(seg[0], seg[1], ws):
+                got[(int(a), int(b))] = got.get((int(a), int(b)), 0) + int(sign * x)
+            assert got == want
             assert list(got) == list(dict.fromkeys(keys))                              # first-occurrence order
 
 
