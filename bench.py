@@ -461,7 +461,9 @@ def main() -> None:
                        "global_batch_graphs": GRAPHS_PER_STEP * world, "parallelism": f"dp{world}", "setup_steps": PRIME_STEPS, "index_rng": a.rng,
                        "index_draws": ("native (csrc_host/hostdraw.cpp)" if (a.rng == "reference" and hostdraw() is not None) else
                                        "device (csrc/augment.hip; negatives on the host)" if a.rng == "device" else "python/numpy"),
-                       "cross_stream_sync": "gates" if engine.use_gates else "events", "gates_verified_under_communicator": gates_checked,
+                       "cross_stream_sync": "gates" if engine.use_gates else "events",
+                       "lp_rows": ("one per unordered pair through the 768->256 layer; dropout mask, score and BCE term per ORDERED row (gmp_lp_pair_*)"
+                                   if engine.lp_merge else "the reference's ordered list (GMP_LP_MERGE=0)"), "gates_verified_under_communicator": gates_checked,
                        "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                        "devices_visible": torch.cuda.device_count(),
                        "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},

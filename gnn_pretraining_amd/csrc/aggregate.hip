@@ -400,11 +400,11 @@ int launch_ldstile144(const float* x, const int* rowptr, const int* col, const f
     constexpr int SBV = 1024, TILEV = 144, CCAPV = 2048;
     auto kern = gin_aggregate_ldstile_kernel<SBV, TILEV, CCAPV, true, DOT>;
     const size_t lds = (size_t)TILEV * 1024 + (size_t)CCAPV * 4 + (size_t)(TILEV + 16) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};        // one bit per device (gnnmp_internal.h)
+    if (!gmp::lds_attr_done(attr_set)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_ldstile: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        gmp::lds_attr_mark(attr_set);
     }
     const int64_t ntiles = (N + TILEV - 1) / TILEV;
     const int blocks = 256;
@@ -464,11 +464,11 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
         do {                                                                                                          \
             auto kern = gin_aggregate_ldstile_kernel<SBV, TILEV, CCAPV, NTV>;                                         \
             const size_t lds = (size_t)TILEV * 1024 + (size_t)CCAPV * 4 + (size_t)(TILEV + 16) * 4;                   \
-            static bool attr_set = false;                                                                             \
-            if (!attr_set) {                                                                                          \
+            static std::atomic<uint64_t> attr_set{0};                                                                 \
+            if (!gmp::lds_attr_done(attr_set)) {                                                                      \
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_ldstile: LDS attribute: %s", hipGetErrorString(e)); \
-                attr_set = true;                                                                                      \
+                gmp::lds_attr_mark(attr_set);                                                                         \
             }                                                                                                         \
             const int64_t ntiles = (N + TILEV - 1) / TILEV;                                                           \
             int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \

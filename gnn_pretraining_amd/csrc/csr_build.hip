@@ -341,11 +341,11 @@ extern "C" int gmp_csr_build(const int64_t* ei, int64_t N, int64_t E, int32_t* r
 
     if (N <= SMALL_MAX_N) {
         constexpr int LDS_INTS = (160 * 1024 - SMALL_THREADS * 4 - 256) / 4;    // 160 KiB minus the static scan array
-        static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_set{0};   // > 64 KiB of dynamic LDS needs the opt-in once per device (gnnmp_internal.h)
+        if (!gmp::lds_attr_done(attr_set)) {
             (void)hipFuncSetAttribute((const void*)csr_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_INTS * 4);
             (void)hipFuncSetAttribute((const void*)csr_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_INTS * 4);
-            attr_set = true;
+            gmp::lds_attr_mark(attr_set);
         }
         if (2 * N + 1 + E <= LDS_INTS) {
             hipLaunchKernelGGL(csr_small_kernel<true>, dim3(both ? 2 : 1), dim3(SMALL_THREADS), (size_t)(2 * N + 1 + E) * sizeof(int), stream,
@@ -401,11 +401,11 @@ extern "C" int gmp_csr_build_segmented(const int64_t* edge_index, int64_t N, int
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "csr_build_segmented: memset");
     const size_t lds = (size_t)(2 * max_seg_rows + max_seg_edges + 2) * sizeof(int);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)csr_segmented_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    static std::atomic<uint64_t> attr_set{0};            // once per device, for the largest segment the check above admits
+    if (!gmp::lds_attr_done(attr_set)) {
+        if (hipFuncSetAttribute((const void*)csr_segmented_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - SEG_THREADS * 4 - 256) != hipSuccess)
             return gmp::fail(GMP_ERR_LAUNCH, "csr_build_segmented: LDS attribute");
-        attr_bytes = lds;
+        gmp::lds_attr_mark(attr_set);
     }
     hipLaunchKernelGGL(csr_segmented_kernel, dim3((unsigned)num_segments, both ? 2 : 1), dim3(SEG_THREADS), lds, st, edge_index, (int)N, (int)E,
                        seg_row_ptr, seg_edge_ptr, rowptr, col, perm, rowptr_t, col_t, perm_t, status);

@@ -390,11 +390,13 @@ template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
 int launch_pipe_cfg(const GemmArgs& g, int tiles_m, int tiles_n, int z, hipStream_t st) {
     using C = g2::Cfg<TM, TN, A_KC, B_KC, STAGES>;
     auto kern = g2::gemm_pipe_kernel<TM, TN, A_KC, B_KC, STAGES>;
-    static bool attr_set = false;            // a workgroup may ask for up to 160 KiB of LDS once the function says so
-    if (!attr_set) {
+    // a workgroup may ask for up to 160 KiB of LDS once the function says so -- per DEVICE (the attribute belongs to the device's copy of
+    // the function): one bit per device ordinal, set after the call succeeded there; racing threads at worst both make the (idempotent) call
+    static std::atomic<uint64_t> attr_set{0};
+    if (!gmp::lds_attr_done(attr_set)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return gmp::fail(GMP_ERR_LAUNCH, "gemm_pipe: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-        attr_set = true;
+        gmp::lds_attr_mark(attr_set);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), 1, (unsigned)z), dim3(g2::THREADS), C::LDS_BYTES, st, g, tiles_m, tiles_n);
     return gmp::check_launch("gemm_pipe_kernel");
@@ -478,11 +480,11 @@ int launch_seg_cfg(const GemmArgs& g, const g2::SegBn& e, int S, hipStream_t st)
     using C = g2::SegCfg<TM, 1, WM, true, B_KC, SEG_STAGES>;
     static_assert(C::LDS_BYTES <= 160 * 1024, "segment tile does not fit the LDS");
     auto kern = g2::gemm_seg_bn_kernel<TM, 1, WM, true, B_KC, SEG_STAGES, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};
+    if (!gmp::lds_attr_done(attr_set)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return gmp::fail(GMP_ERR_LAUNCH, "gemm_seg_bn: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-        attr_set = true;
+        gmp::lds_attr_mark(attr_set);
     }
     const int tiles_n = (int)(g.N / C::BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)(S * tiles_n)), dim3(g2::THREADS), C::LDS_BYTES, st, g, e, tiles_n);

@@ -1,6 +1,8 @@
 // Internal helpers shared by the libgnnmp kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -29,6 +31,13 @@ inline int check_launch(const char* what) {
 }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the DEVICE's copy of a function: a launcher keeps one "done" bit per device
+// ordinal (std::atomic<uint64_t>, function-local static) instead of a process-wide bool -- a process driving a second GPU would otherwise
+// skip the call there and fail to launch its > 64 KiB tiles.  Racing threads at worst both make the (idempotent) call; ordinals >= 64 repeat it.
+inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+inline bool lds_attr_done(const std::atomic<uint64_t>& m) { const int d = cur_device(); return d < 64 && ((m.load(std::memory_order_acquire) >> d) & 1ull); }
+inline void lds_attr_mark(std::atomic<uint64_t>& m) { const int d = cur_device(); if (d < 64) m.fetch_or(1ull << d, std::memory_order_release); }
 
 // ---- Philox4x32-10 (counter-based RNG for dropout; mask is regenerated in the
 // backward pass from (seed, stream, element) instead of being stored) ----------

@@ -12,8 +12,9 @@ Here a dataset is a `GraphStore` (data/store.py: five flat arrays in one data.sa
 (`x`, `edge_index` with graph-LOCAL ids, `y`, `num_nodes`), so it runs on real `torch_geometric.data.Data` lists in the
 reference's environment -- where this module needs nothing but torch and safetensors -- and on this repository's own `Data`
 objects (tests/test_data.py round-trips it without PyG).  `export_processed_tree` walks a whole data/processed directory;
-it unpickles with torch.load(weights_only=False) and is therefore meant for files the caller generated himself
-(`python -m src.data.data_setup`), never for downloaded ones.  INTEGRATION.md section 5 shows the call."""
+splits.pt / graph_properties.pt are read with the weights-only loader; data.pt (a pickle of objects) only behind an explicit
+`allow_pickle=True` -- for files the caller generated himself (`python -m src.data.data_setup`), never for downloaded ones.
+INTEGRATION.md section 5 shows the call."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -56,13 +57,25 @@ def export_dataset(graphs: Sequence, splits: Dict[str, Tensor], graph_properties
     return store
 
 
+def _load_plain(path: Path):
+    """A .pt file that holds only tensors / dicts / lists of tensors (splits.pt, graph_properties.pt): nothing in it executes."""
+    return torch.load(path, weights_only=True)
+
+
 def export_processed_tree(processed_dir: Union[str, Path], out_root: Union[str, Path],
-                          load: Optional[Callable[[Path], object]] = None) -> Dict[str, GraphStore]:
-    """Every dataset directory under the reference's data/processed -> out_root/D.  `load(path)` reads one .pt file (default:
-    torch.load(path, weights_only=False) -- pickles: only for files you produced yourself)."""
-    load = load or (lambda p: torch.load(p, weights_only=False))
+                          load: Optional[Callable[[Path], object]] = None, allow_pickle: bool = False) -> Dict[str, GraphStore]:
+    """Every dataset directory under the reference's data/processed -> out_root/D.
+
+    splits.pt and graph_properties.pt are plain tensors / dicts and are read with torch.load(weights_only=True).  data.pt is a pickled list
+    of Data objects: reading it EXECUTES whatever the file contains, so it is never done by default -- pass `allow_pickle=True` (files you
+    produced yourself with `python -m src.data.data_setup`, never downloaded ones), or `load=` with a reader of your own for data.pt."""
+    if load is None:
+        if not allow_pickle:
+            raise ValueError("export_processed_tree: data.pt is a pickle of Data objects and unpickling executes code from the file. "
+                             "Pass allow_pickle=True only for files you generated yourself, or load=<your reader of data.pt>.")
+        load = lambda p: torch.load(p, weights_only=False)          # noqa: E731  (explicit opt-in above)
     out = {}
     for d in sorted(p for p in Path(processed_dir).iterdir() if p.is_dir() and (p / "data.pt").exists()):
-        gp = load(d / "graph_properties.pt") if (d / "graph_properties.pt").exists() else None
-        out[d.name] = export_dataset(load(d / "data.pt"), load(d / "splits.pt"), gp, Path(out_root) / d.name)
+        gp = _load_plain(d / "graph_properties.pt") if (d / "graph_properties.pt").exists() else None
+        out[d.name] = export_dataset(load(d / "data.pt"), _load_plain(d / "splits.pt"), gp, Path(out_root) / d.name)
     return out

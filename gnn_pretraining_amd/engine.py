@@ -634,6 +634,20 @@ class StepEngine:
             self._neg_native.setstate(torch.tensor(self.neg_rng.getstate()[1], dtype=torch.long))
         return self._neg_native.negative_edges(*_host_tensors(b)).numpy()
 
+    def rng_state(self) -> Dict[str, object]:
+        """Everything random the engine owns besides the caller's torch.Generator, as plain Python data (pretrain() stores it in the checkpoint
+        next to the generator state): the link-prediction negatives' Python-random stream and the device-draw sequence numbers."""
+        return {"neg_rng": self.sync_neg_rng().getstate(), "draw_seq": dict(getattr(self, "_draw_seq", {True: 0, False: 0})),
+                "step_count": int(self.step_count)}
+
+    def set_rng_state(self, st: Dict[str, object]) -> None:
+        v, key, g = st["neg_rng"]
+        self.neg_rng.setstate((int(v), tuple(int(x) for x in key), g))
+        if self._neg_native is not None:
+            self._neg_native.setstate(torch.tensor(self.neg_rng.getstate()[1], dtype=torch.long))
+        self._draw_seq = {bool(k): int(n) for k, n in st.get("draw_seq", {}).items()} or {True: 0, False: 0}
+        self.step_count = int(st.get("step_count", self.step_count))
+
     def sync_neg_rng(self) -> random.Random:
         """Write the native stream's state back into self.neg_rng (checkpointing / tests) and return it."""
         if self._neg_native is not None:
@@ -699,8 +713,15 @@ class StepEngine:
         collect_draws() waits on."""
         if not hasattr(self, "_draw_slots"):
             self._draw_slots, self._draw_count, self._draw_ws, self._draw_graveyard = [], 0, None, []
-        k = self._draw_count
+            self._draw_seq = {True: 0, False: 0}
+        k = self._draw_count                       # ticket number: ring slot and flag value (every enqueue, probes and evaluation included)
         self._draw_count += 1
+        # The random stream is a function of (engine seed, mode, how many inputs of that mode were drawn), not of the ticket number:
+        # evaluation passes and verify_gates' probe steps (which rewinds its own) leave the training sequence where it was
+        mode = bool(self.model.training)
+        seq = self._draw_seq[mode]
+        self._draw_seq[mode] = seq + 1
+        self._bury()                               # free outgrown buffers the aux stream has passed
         lay, off = [], 0
 
         def take(nbytes: int) -> int:
@@ -732,13 +753,13 @@ class StepEngine:
         slot = self._draw_slots[slot_id]
         if slot is None or slot["dev"].numel() < total:
             cap = max(total * 2, 1 << 20)
-            self._draw_graveyard.append(slot)
+            self._bury(slot)
             slot = self._draw_slots[slot_id] = {"dev": torch.empty(cap, dtype=torch.uint8, device=self.device),
                                                 "pin": torch.empty(cap, dtype=torch.uint8).pin_memory(),
                                                 "flag": torch.zeros(4, dtype=torch.int32).pin_memory()}
         lib, aux = self.lib, self.aux_stream.cuda_stream
         base = slot["dev"].data_ptr()
-        seed = (self.seed * 1000003 + 0x5bd1e995 * (k + 1)) & (2 ** 64 - 1)
+        seed = (self.seed * 1000003 + 0x5bd1e995 * (seq + 1) + (0 if mode else 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
         if True:
             # every (task, domain) job of the step in three launches (masks | views | emit): on the aux stream beside a running step the
             # twenty per-job launches cost that step 0.3 ms
@@ -753,7 +774,7 @@ class StepEngine:
             if ws_need and (self._draw_ws is None or self._draw_ws.numel() < ws_need):
                 # (kernels of earlier tickets may still be using the old one on the aux stream: keep it alive.  One region per JOB -- the
                 # jobs of a ticket run concurrently; tickets follow each other on the aux stream and share the regions)
-                self._draw_graveyard.append(self._draw_ws)
+                self._bury(self._draw_ws)
                 self._draw_ws = torch.empty(max(2 * ws_need, 4 * lib.gmp_aug_workspace_bytes(self.max_rows, self.max_edges, 1024)),
                                             dtype=torch.uint8, device=self.device)
             ws_base = self._draw_ws.data_ptr() if ws_need else 0
@@ -778,6 +799,15 @@ class StepEngine:
             self._chk(lib.gmp_upload(1, src, dst, (C.c_int64 * 1)((total + 15) // 16 * 16), aux), "draw results -> pinned host")
             self._chk(lib.gmp_gate_open(slot["flag"].data_ptr(), k + 1, aux), "draw flag")
         return DrawTicket(slot, lay, k + 1)
+
+    def _bury(self, obj=None) -> None:
+        """Outgrown draw slots / workspaces may still be in use by tickets already on the aux stream: each is kept with an event recorded
+        there and dropped once the stream has passed it (they used to live as long as the engine)."""
+        if obj is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.aux_stream)
+            self._draw_graveyard.append((obj, ev))
+        self._draw_graveyard = [(o, e) for o, e in self._draw_graveyard if not e.query()]
 
     def collect_draws(self, inp: StepInputs, ticket: "DrawTicket") -> Dict[str, object]:
         """Wait for a ticket's flag (a word in pinned host memory the GPU sets behind its copy: no HIP call, no stream sync) and wrap
@@ -1776,8 +1806,11 @@ class StepEngine:
         host_state = (self.step_count, self._bn_calls, list(self._bn_calls_dom), self._nprng, dict(self.host_ms))
         # the link-prediction negatives draw from a stream of their own (neg_rng / its native twin): both passes must see the same one
         neg_state = (self.neg_rng.getstate(), self._neg_native.getstate().clone() if self._neg_native is not None else None)
+        seq_state = dict(getattr(self, "_draw_seq", {}))
 
         def rewind_negatives() -> None:
+            if seq_state:
+                self._draw_seq = dict(seq_state)           # device draws: both passes (and the run after them) see the same sequence
             self.neg_rng.setstate(neg_state[0])
             if self._neg_native is not None and neg_state[1] is not None:
                 self._neg_native.setstate(neg_state[1])

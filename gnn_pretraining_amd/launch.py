@@ -1,6 +1,6 @@
 """Start the N ranks of a one-node data-parallel job as CHILD processes (one process per GPU).
 
-`python bench.py --gpus N` (and `run_pretrain.py --world-size N`) call this before anything in the parent has touched
+`python bench.py --gpus N` calls this before anything in the parent has touched
 the GPU: on this pool a process that has initialised HIP must never be replaced by another program, and
 torch.cuda.device_count() -- the only device query made here -- does not initialise it.  The reference has no counterpart
 (its only parallelism is job fan-out, run_pretrain.py:57-58); the rank environment is the one torch.distributed.run sets
@@ -83,8 +83,16 @@ def launch_ranks(n: int, cmd: Sequence[str], ndev: Optional[int] = None, log: Ca
     return rc, line, rcs
 
 
+DEFAULT_TIMEOUT_S = 1800.0
+
+
 def run_and_relay(n: int, cmd: Sequence[str], log: Callable[[str], None], expect_key: str = "n_gpus", **kw) -> int:
-    """launch_ranks + the check the bench contract needs: the relayed line must report n ranks under `expect_key`."""
+    """launch_ranks + the check the bench contract needs: the relayed line must report n ranks under `expect_key`.
+    A job in which EVERY rank hangs (say, in its first collective) exits no rank, so nothing above would ever react: the launch has a
+    finite time limit (GMP_LAUNCH_TIMEOUT_S, default 30 minutes; `timeout_s=` overrides), after which the exact child PIDs are terminated
+    and the call returns non-zero."""
+    if kw.get("timeout_s") is None:
+        kw["timeout_s"] = float(os.environ.get("GMP_LAUNCH_TIMEOUT_S", DEFAULT_TIMEOUT_S))
     rc, line, _ = launch_ranks(n, cmd, log=log, is_result=lambda ln: ln.startswith("{") and f'"{expect_key}"' in ln, **kw)
     if rc:
         return rc

@@ -282,8 +282,12 @@ def pretrain(cfg: PretrainConfig, epochs: int = EPOCHS, steps_per_epoch: Optiona
         logger.log(val, global_step[0])
         if val["val/loss/total"] < best:
             best, stale = val["val/loss/total"], 0
-            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
-                        "val_metrics": {k: v for k, v in val.items() if k.startswith("val/")}}, path)
+            ckpt = {"epoch": epoch, "model_state_dict": model.state_dict(),
+                    "val_metrics": {k: v for k, v in val.items() if k.startswith("val/")}}           # the reference's three keys (pretrain.py:263-267)
+            # one key more, plain data (loads under weights_only=True; load_pretrained_weights reads model_state_dict only): the random
+            # streams a resumed run needs -- the shared generator and, on the engine, the negatives' stream and the device-draw sequence
+            ckpt["rng_state"] = {"generator": generator.get_state(), "engine": engine.rng_state() if engine is not None else None}
+            torch.save(ckpt, path)
         else:
             stale += 1
         if stale >= int(epochs * PATIENCE_FRACTION):

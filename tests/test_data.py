@@ -291,7 +291,7 @@ def test_export_bridge_refuses_global_edge_ids(tmp_path):
 
 def test_export_tree_walks_the_reference_layout(tmp_path):
     """data/processed/{D}/{data,splits,graph_properties}.pt -> {D}/*.safetensors, with the .pt files written by torch.save the way
-    data_setup.save_processed_data does (here: our own picklable stand-ins, loaded with the default loader)."""
+    data_setup.save_processed_data does (here: our own picklable stand-ins; the object pickle needs the explicit opt-in, the two tensor files go through the weights-only loader)."""
     from gnn_pretraining_amd.data.export import export_processed_tree
     gen = _gen(23)
     src = tmp_path / "processed"
@@ -301,7 +301,9 @@ def test_export_tree_walks_the_reference_layout(tmp_path):
         torch.save(graphs, src / name / "data.pt")
         torch.save({"train": torch.arange(0, 9), "val": torch.arange(9, 12)}, src / name / "splits.pt")
         torch.save(torch.randn(12, 12, generator=gen), src / name / "graph_properties.pt")
-    out = export_processed_tree(src, tmp_path / "export")
+    with pytest.raises(ValueError, match="allow_pickle"):            # unpickling objects is never the default
+        export_processed_tree(src, tmp_path / "export")
+    out = export_processed_tree(src, tmp_path / "export", allow_pickle=True)
     assert sorted(out) == ["ENZYMES", "NCI1"]
     for name in out:
         st = GraphStore.load(tmp_path / "export" / name)

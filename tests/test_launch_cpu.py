@@ -47,5 +47,15 @@ def test_a_line_that_reports_the_wrong_rank_count_is_refused(capsys):
     assert capsys.readouterr().out == ""         # nothing relayed: never an n_gpus:1 line for a 2-rank launch
 
 
+def test_a_job_in_which_every_rank_hangs_is_ended_by_the_default_time_limit(monkeypatch):
+    """No rank exits, so only the time limit can end the launch: run_and_relay has a finite default (GMP_LAUNCH_TIMEOUT_S)."""
+    import time
+    assert launch.DEFAULT_TIMEOUT_S < float("inf")
+    monkeypatch.setenv("GMP_LAUNCH_TIMEOUT_S", "3")
+    t0 = time.time()
+    rc = launch.run_and_relay(2, [sys.executable, STUB, "hang"], log=lambda m: None, ndev=0)
+    assert rc != 0 and time.time() - t0 < 60
+
+
 def test_backend_choice():
     assert launch.pick_backend(8, 8) == "nccl" and launch.pick_backend(2, 1) == "gloo" and launch.pick_backend(2, 0) == "gloo"
