@@ -63,7 +63,7 @@ class AugViewsJob(C.Structure):          # gmp_aug_views_job
 
 class BnConfig(C.Structure):
     _fields_ = [("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float), ("momentum", C.c_float),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint32)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("seed_dev", C.c_void_p)]
 
 
 _SIGS: Dict[str, tuple] = {
@@ -90,9 +90,6 @@ _SIGS: Dict[str, tuple] = {
     "gmp_bn_workspace_bytes": (sz, [i64, i32, i32, i64]),
     "gmp_bn_fwd": (C.c_int, [p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, C.POINTER(BnConfig), p, sz, p]),
     "gmp_bn_param_grads": (C.c_int, [p, i32, i32, p, p, p, p, p, i32, p]),
-    "gmp_linear_bn_supported": (C.c_int, [i32, i64, i32, i32]),
-    "gmp_linear_bn_fwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, i32, p, p, p, p, p, p, C.POINTER(BnConfig), p]),
-    "gmp_linear_bn_bwd_input": (C.c_int, [p, p, p, p, i32, i64, i64, i32, i32, p, p, p, p, p, p, sz, C.POINTER(BnConfig), p]),
     "gmp_bn_running_update_batch": (C.c_int, [i32, p, i32, p, p, p, p, p, p, p, p]),
     "gmp_bn_running_update": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p]),
     "gmp_bn_bwd": (C.c_int, [p, p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, p, p, p, p, p, i32,
@@ -134,6 +131,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_gate_wait": (C.c_int, [p, C.c_uint64, i32, p, p]),
     "gmp_gate_open": (C.c_int, [p, i32, p]),
     "gmp_gate_set_timeout": (C.c_int, [C.c_double]),
+    "gmp_counter_add": (C.c_int, [p, C.c_uint64, p]),
     "gmp_aug_workspace_bytes": (sz, [i64, i64, i32]),
     "gmp_aug_node_masks": (C.c_int, [p, p, i32, i64, C.c_uint64, C.c_uint32, p, p]),
     "gmp_aug_node_masks_batch": (C.c_int, [C.POINTER(AugMasksJob), i32, i64, C.c_uint64, p]),

@@ -66,6 +66,9 @@ __device__ __forceinline__ float4 load_u(const BnArgs& a, int64_t off) {
     return u;
 }
 
+// dropout seed of this launch: the configured one, plus the device word when the caller passed one (hipGraph replays: gnnmp.h gmp_bn_config)
+__device__ __forceinline__ uint64_t bn_seed(const BnArgs& a) { return a.cfg.seed_dev ? a.cfg.seed + *a.cfg.seed_dev : a.cfg.seed; }
+
 // y = dropout(relu(gamma*xhat+beta)) for one float4; returns the pre-dropout activation mask in `pos`
 __device__ __forceinline__ float4 bn_apply(const BnArgs& a, float4 u, float4 mean, float4 rstd, float4 gam, float4 bet,
                                            int64_t elem_quad, float4* gate) {
@@ -77,7 +80,7 @@ __device__ __forceinline__ float4 bn_apply(const BnArgs& a, float4 u, float4 mea
         y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
     }
     if (a.cfg.dropout_p > 0.f) {
-        float4 d = gmp::dropout_scale4(a.cfg.seed, a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p,
+        float4 d = gmp::dropout_scale4(bn_seed(a), a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p,
                                        1.f / (1.f - a.cfg.dropout_p));
         y = mul4(y, d);
         g = mul4(g, d);
@@ -303,7 +306,7 @@ __device__ __forceinline__ float4 gate_of(const BnArgs& a, float4 xh, float4 gam
         g = make_float4(y.x > 0.f, y.y > 0.f, y.z > 0.f, y.w > 0.f);
     }
     if (a.cfg.dropout_p > 0.f)
-        g = mul4(g, gmp::dropout_scale4(a.cfg.seed, a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p, 1.f / (1.f - a.cfg.dropout_p)));
+        g = mul4(g, gmp::dropout_scale4(bn_seed(a), a.cfg.stream_id, (uint64_t)elem_quad, a.cfg.dropout_p, 1.f / (1.f - a.cfg.dropout_p)));
     return g;
 }
 

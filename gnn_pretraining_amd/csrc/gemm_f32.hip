@@ -472,91 +472,6 @@ void signal_on_next_gemm(int32_t* flag, int value) {
 bool signal_pending() { return t_sig_flag != nullptr; }
 }  // namespace gmp
 
-// ---- Linear + BatchNorm of short segments in one launch (gemm_pipe.h gemm_seg_bn_kernel) ------------------------------------
-namespace {
-constexpr int SEG_STAGES = 3;
-template <int TM, int WM, bool B_KC, int EPI>
-int launch_seg_cfg(const GemmArgs& g, const g2::SegBn& e, int S, hipStream_t st) {
-    using C = g2::SegCfg<TM, 1, WM, true, B_KC, SEG_STAGES>;
-    static_assert(C::LDS_BYTES <= 160 * 1024, "segment tile does not fit the LDS");
-    auto kern = g2::gemm_seg_bn_kernel<TM, 1, WM, true, B_KC, SEG_STAGES, EPI>;
-    static std::atomic<uint64_t> attr_set{0};
-    if (!gmp::lds_attr_done(attr_set)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-            return gmp::fail(GMP_ERR_LAUNCH, "gemm_seg_bn: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-        gmp::lds_attr_mark(attr_set);
-    }
-    const int tiles_n = (int)(g.N / C::BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(S * tiles_n)), dim3(g2::THREADS), C::LDS_BYTES, st, g, e, tiles_n);
-    return gmp::check_launch("gemm_seg_bn_kernel");
-}
-// wide = 64-column tiles of 2 x 2 waves (segments up to 320 rows); narrow = 32-column tiles of 4 x 1 waves (up to 384 rows).
-// Narrow when the wide grid would leave a third of the CUs without a block (one block per CU: the grid is one wave of blocks).
-bool seg_wide(int S, int64_t N) { return N % 64 == 0 && (int64_t)S * (N / 64) >= 160; }
-int64_t seg_max_rows(bool wide) { return wide ? 320 : 384; }
-template <bool B_KC, int EPI>
-int launch_seg(const GemmArgs& g, const g2::SegBn& e, int S, int64_t max_seg, hipStream_t st) {
-    if (seg_wide(S, g.N)) {
-        switch ((int)((max_seg + 63) / 64)) {
-            case 0: case 1: return launch_seg_cfg<1, 2, B_KC, EPI>(g, e, S, st);
-            case 2: return launch_seg_cfg<2, 2, B_KC, EPI>(g, e, S, st);
-            case 3: return launch_seg_cfg<3, 2, B_KC, EPI>(g, e, S, st);
-            case 4: return launch_seg_cfg<4, 2, B_KC, EPI>(g, e, S, st);
-            default: return launch_seg_cfg<5, 2, B_KC, EPI>(g, e, S, st);
-        }
-    }
-    switch ((int)((max_seg + 127) / 128)) {
-        case 0: case 1: return launch_seg_cfg<1, 4, B_KC, EPI>(g, e, S, st);
-        case 2: return launch_seg_cfg<2, 4, B_KC, EPI>(g, e, S, st);
-        default: return launch_seg_cfg<3, 4, B_KC, EPI>(g, e, S, st);
-    }
-}
-}  // namespace
-
-extern "C" int gmp_linear_bn_supported(int num_segments, int64_t max_seg_rows, int in_features, int out_features) {
-    if (!pipe_enabled() || num_segments < 1 || in_features < 64 || in_features % g2::BK || out_features < 32 || out_features % 32) return 0;
-    static const bool off = getenv("GMP_FUSED_BN") && getenv("GMP_FUSED_BN")[0] == '0';
-    return !off && max_seg_rows >= 1 && max_seg_rows <= seg_max_rows(seg_wide(num_segments, out_features));
-}
-
-extern "C" int gmp_linear_bn_fwd(const float* x, const float* weight, const float* bias, const float* residual, const int32_t* seg_ptr,
-                                 int num_segments, int64_t max_seg_rows, int64_t rows, int in_features, int out_features,
-                                 const float* gamma, const float* beta, float* save_mean, float* save_rstd, float* u, float* y,
-                                 const gmp_bn_config* cfg, gmp_stream_t stream) {
-    if (!cfg || !cfg->training) return gmp::fail(GMP_ERR_ARG, "linear_bn_fwd: batch statistics only (training mode)");
-    if (!gmp_linear_bn_supported(num_segments, max_seg_rows, in_features, out_features))
-        return gmp::fail(GMP_ERR_ARG, "linear_bn_fwd: shape not covered (segments of %lld rows, %d -> %d)", (long long)max_seg_rows, in_features, out_features);
-    if (rows <= 0) return GMP_OK;
-    if (!x || !weight || !seg_ptr || !gamma || !beta || !save_mean || !save_rstd || !u || !y) return gmp::fail(GMP_ERR_ARG, "linear_bn_fwd: null pointer");
-    if (!aligned16(x) || !aligned16(weight) || !aligned16(u) || !aligned16(y)) return gmp::fail(GMP_ERR_ARG, "linear_bn_fwd: operands must be 16-byte aligned");
-    GemmArgs g{x, weight, bias, y, rows, out_features, in_features, in_features, in_features, out_features, 1.f, 0, 0, 1, nullptr, 1, 1};
-    take_signal(g);
-    g.vecC = 1;
-    g2::SegBn e{seg_ptr, gamma, beta, save_mean, save_rstd, residual, u, nullptr, cfg->eps, cfg->dropout_p, cfg->relu, cfg->seed, cfg->stream_id};
-    return launch_seg<true, g2::EPI_BN_FWD>(g, e, num_segments, max_seg_rows, (hipStream_t)stream);
-}
-
-extern "C" int gmp_linear_bn_bwd_input(const float* g_out, const float* weight, const float* x, const int32_t* seg_ptr, int num_segments,
-                                       int64_t max_seg_rows, int64_t rows, int out_features, int channels, const float* gamma,
-                                       const float* beta, const float* save_mean, const float* save_rstd, float* g_x,
-                                       void* bn_bwd_workspace, size_t workspace_bytes, const gmp_bn_config* cfg, gmp_stream_t stream) {
-    if (!cfg || !cfg->training || cfg->dropout_p > 0.f)
-        return gmp::fail(GMP_ERR_ARG, "linear_bn_bwd_input: training-mode BatchNorm without dropout only");
-    if (!gmp_linear_bn_supported(num_segments, max_seg_rows, out_features, channels) || channels % 4)
-        return gmp::fail(GMP_ERR_ARG, "linear_bn_bwd_input: shape not covered (segments of %lld rows, %d <- %d)", (long long)max_seg_rows, channels, out_features);
-    if (workspace_bytes < (size_t)num_segments * 2 * channels * sizeof(float)) return gmp::fail(GMP_ERR_ARG, "linear_bn_bwd_input: workspace too small");
-    if (rows <= 0) return GMP_OK;
-    if (!g_out || !weight || !x || !seg_ptr || !gamma || !beta || !save_mean || !save_rstd || !g_x || !bn_bwd_workspace)
-        return gmp::fail(GMP_ERR_ARG, "linear_bn_bwd_input: null pointer");
-    if (!aligned16(g_out) || !aligned16(weight) || !aligned16(g_x)) return gmp::fail(GMP_ERR_ARG, "linear_bn_bwd_input: operands must be 16-byte aligned");
-    GemmArgs g{g_out, weight, nullptr, g_x, rows, channels, out_features, out_features, channels, channels, 1.f, 0, 0, 1, nullptr, 1, 1};
-    take_signal(g);
-    g.vecC = 1;
-    g2::SegBn e{seg_ptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_rstd), nullptr, const_cast<float*>(x),
-                (float*)bn_bwd_workspace, cfg->eps, 0.f, cfg->relu, cfg->seed, cfg->stream_id};
-    return launch_seg<false, g2::EPI_BN_BWD>(g, e, num_segments, max_seg_rows, (hipStream_t)stream);
-}
-
 extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     (void)mode;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -603,8 +518,14 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
 #ifdef GMP_PIPE_DEBUG
     if (getenv("GMP_PIPE_NOSTORE")) g.accumulate |= 0x100;
 #endif
-    if (mode != GMP_GEMM_TN && g.splitk == 1 && M >= 1024 && N >= 64 && pipe_ok(mode, g))
-        return launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, 1, st);
+    if (mode != GMP_GEMM_TN && M >= 1024 && N >= 64 && pipe_ok(mode, g) && (g.splitk == 1 || N % 4 == 0)) {   // (slices are stored as float4 rows of N)
+        if (g.splitk == 1) return launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, 1, st);
+        // few output tiles and a long K (the caller handed over a workspace): K-slices of the pipelined kernel, summed in slice order
+        if (int rc = launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, g.splitk, st)) return rc;
+        const int blocks = (int)std::min<int64_t>((M * N + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+        return gmp::check_launch("splitk_reduce_kernel");
+    }
     static const bool nofast = getenv("GMP_GEMM_NOFAST") != nullptr;
     // with split-K (TN) slices start at multiples of BK inside [0,K): the fast loader's k handling covers that
     const bool fast = !nofast && fast_ok<BK_DEFAULT>(mode, g, M);

@@ -224,6 +224,15 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
             if (biasp) biasp += g.biasoff[grp];
         }
     }
+    // split-K of the NT / NN forms (few output tiles, long K: the fine-tune encoder's 2,708 x 1,440 -> 256): slice z takes a run of whole
+    // K-steps and leaves its partial tile in g.partial[z] ([M, N] each); splitk_reduce_kernel adds the slices in order and applies the epilogue
+    const bool ksplit = !IS_TN && g.groups == 0 && g.splitk > 1;
+    if (ksplit) {
+        const int64_t steps = g.K / BK, per = (steps + g.splitk - 1) / g.splitk;
+        kbeg = (int64_t)blockIdx.z * per * BK;
+        kend = kbeg + per * BK < g.K ? kbeg + per * BK : g.K;
+        Cp = g.partial + (int64_t)blockIdx.z * g.M * g.N;
+    }
     const int64_t klen_total = kend > kbeg ? kend - kbeg : 0;
     const int nfull = (int)(klen_total / BK);
     const int ktail = (int)(klen_total - (int64_t)nfull * BK);       // > 0 only in the weight-gradient form
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
     // float4 row pieces: 4 * TM * TN dwordx4 stores per lane, 1 KiB each.  Same arithmetic per element, in the same order.
     float* out = Cp;
     int64_t ldo = g.ldc;
-    const bool partial = IS_TN && g.groups > 0 && g.gsplit > 1;
+    const bool partial = (IS_TN && g.groups > 0 && g.gsplit > 1) || ksplit;
     if (partial) ldo = g.N;
     constexpr int WR = 32 * TM, WC = 32 * TN;                 // the wave's sub-tile
     const int64_t row0 = m0 + wm * WR, col0 = n0 + wn * WC;
@@ -439,312 +448,6 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
                 out[row * ldo + col] = v;
             }
         }
-}
-
-// =====================================================================================================================
-// Segment GEMM with the BatchNorm fused into its epilogue (short segments: the stacked pre-training step).
-//
-// BatchNorm statistics are sums over the ROWS OF ONE SEGMENT (one reference forward() call), per column.  When a workgroup's
-// output tile covers every row of a segment for its columns, those sums live in the accumulators the GEMM leaves behind, and the
-// separate BatchNorm launch -- one more read and write of the activation, 9-11 us forward / 15-26 us backward on the critical
-// chain of every layer -- disappears into the epilogue:
-//   EPI_BN_FWD  (NT, Linear forward):  u = A W^T + bias (+ residual);  per (segment, column) exact two-pass mean / variance over
-//               the accumulators;  y = dropout(relu(gamma * (u - mean) * rstd + beta));  stores u, y, mean, rstd.
-//   EPI_BN_BWD  (NN, input gradient):  g = G W  is the gradient at the BatchNorm OUTPUT of the layer below;  with that layer's
-//               saved x, mean, rstd:  ga = g * relu_gate,  s1 = sum ga,  s2 = sum ga * xhat,
-//               dx = gamma * rstd * (ga - s1 / n - xhat * s2 / n);  stores dx and (s1, s2) for the parameter gradients.
-// Tile: WM x (4 / WM) waves, each TM x TN blocks of 32 x 32 -> BM = 32 * TM * WM rows (>= the longest segment), BN = 32 * TN *
-// (4 / WM) columns; grid = segments x column tiles (blocks of one segment on one XCD: its rows of A enter one L2).  The main loop
-// is gemm_pipe_kernel's (same ring, same hand-over, same accumulation order per element: u is bit-identical to the plain GEMM's).
-// Arithmetic of the normalisation: batchnorm.hip's (bn_apply / bwd_input), the column sums in a different association.
-struct SegBn {
-    const int32_t* seg_ptr;      // [S + 1]
-    const float* gamma;          // [C]
-    const float* beta;
-    float* mean;                 // [S][C]  FWD: written, BWD: read
-    float* rstd;
-    const float* res;            // FWD: residual added before the normalisation (leading dimension ldc), nullable
-    float* z;                    // FWD: u out (ldc);  BWD: the BatchNorm's input x (read, ldc)
-    float* segsum;               // BWD: [S][2][C]
-    float eps, dropout_p;
-    int relu;
-    uint64_t seed;
-    uint32_t stream_id;
-};
-enum { EPI_BN_FWD = 1, EPI_BN_BWD = 2 };
-
-template <int TM, int TN, int WM, bool A_KC, bool B_KC, int STAGES>
-struct SegCfg {
-    static constexpr int WN = 4 / WM;
-    static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    using OA = Operand<BM, A_KC>;
-    using OB = Operand<BN, B_KC>;
-    static constexpr int STAGE_BYTES = OA::BYTES + OB::BYTES;
-    static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int EPI_BYTES = BM * BN * 4 + 8 * BN * 4 + 2 * WM * BN * 4;      // transposed tile + column parameters + reduction scratch
-    static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-    static constexpr int LOADS = OA::PER_WAVE + OB::PER_WAVE;
-};
-
-template <int TM, int TN, int WM, bool A_KC, bool B_KC, int STAGES, int EPI>
-__global__ __launch_bounds__(THREADS) void gemm_seg_bn_kernel(const GemmArgs g, const SegBn e, int tiles_n) {
-    using C = SegCfg<TM, TN, WM, A_KC, B_KC, STAGES>;
-    constexpr int WN = C::WN, WR = 32 * TM, WC = 32 * TN;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
-    if (g.sig_flag && t == 0 && blockIdx.x == 0) __hip_atomic_store(g.sig_flag, g.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int seg = bid / tiles_n, tile_n = bid - seg * tiles_n;
-    const int64_t m0 = e.seg_ptr[seg], Mrows = e.seg_ptr[seg + 1];
-    const int n = (int)(Mrows - m0);
-    const int64_t n0 = (int64_t)tile_n * C::BN;
-    const int64_t ldc = g.ldc;
-    if (n <= 0) {
-        if (EPI == EPI_BN_BWD && t < C::BN) {
-            e.segsum[((int64_t)seg * 2) * g.N + n0 + t] = 0.f;
-            e.segsum[((int64_t)seg * 2 + 1) * g.N + n0 + t] = 0.f;
-        }
-        return;
-    }
-    const int nsteps = (int)(g.K / BK);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    typename C::OA la;
-    typename C::OB lb;
-    la.init(g.A, g.lda, m0, Mrows, 0, lane, wave, true);
-    lb.init(g.B, g.ldb, n0, g.N, 0, lane, wave);
-    auto stage_ptr = [&](int s) -> char* { return smem + (s % STAGES) * C::STAGE_BYTES; };
-    const unsigned lds0 = lds_address(smem);
-    auto issue = [&](int s) {
-        const unsigned sp = lds0 + (s % STAGES) * C::STAGE_BYTES;
-        la.issue(sp, wave);
-        lb.issue(sp + C::OA::BYTES, wave);
-    };
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nsteps) issue(s);
-
-    float fa0[TM][4], fa1[TM][4], fb0[TN][4], fb1[TN][4];
-    constexpr int NREADS = (A_KC ? TM : 4 * TM) + (B_KC ? TN : 4 * TN), NMFMA = 4 * TM * TN;
-    auto read = [&](const char* st, int sub, float (&fa)[TM][4], float (&fb)[TN][4]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) read_frag<C::BM, A_KC>(st, wm * WR + 32 * i, sub, l31, half, fa[i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) read_frag<C::BN, B_KC>(st + C::OA::BYTES, wn * WC + 32 * j, sub, l31, half, fb[j]);
-    };
-    if (STAGES >= 4 && nsteps >= 3) wait_vmcnt<2 * C::LOADS>();
-    else if (STAGES >= 3 && nsteps >= 2) wait_vmcnt<C::LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    read(stage_ptr(0), 0, fa0, fb0);
-    for (int s = 0; s < nsteps; ++s) {
-        const char* st = stage_ptr(s);
-        read(st, 1, fa1, fb1);
-        mfma_sub<TM, TN, false>(acc, fa0, fb0, 0, half, BK);
-        sched_sub<NREADS, NMFMA>();
-        read(st, 2, fa0, fb0);
-        mfma_sub<TM, TN, false>(acc, fa1, fb1, 1, half, BK);
-        sched_sub<NREADS, NMFMA>();
-        read(st, 3, fa1, fb1);
-        mfma_sub<TM, TN, false>(acc, fa0, fb0, 2, half, BK);
-        sched_sub<NREADS, NMFMA>();
-        if (s + 1 < nsteps) {
-            if (STAGES >= 4 && s + 2 < nsteps) wait_vmcnt<C::LOADS>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1);
-            read(stage_ptr(s + 1), 0, fa0, fb0);
-        }
-        mfma_sub<TM, TN, false>(acc, fa1, fb1, 3, half, BK);
-    }
-
-    // ---- epilogue: element (i, j, r) of this lane is row m0 + wm * WR + 32 i + rowof(r), column n0 + wn * WC + 32 j + l31
-    float* tile_all = reinterpret_cast<float*>(smem);                       // [4 waves][WR][WC]
-    float* colp = tile_all + C::BM * C::BN;                                 // [8][BN] column parameters for the row phase
-    float* red = colp + 8 * C::BN;                                          // [2][WM][BN]
-    const int rbase = wm * WR + 4 * half;
-    auto rowof = [&](int i, int r) { return rbase + 32 * i + (r & 3) + 8 * (r >> 2); };          // row inside the segment
-    const float inv_n = 1.f / (float)n;
-    __builtin_amdgcn_s_barrier();                                           // the ring is free: every wave has read its last stage
-
-    // column sum over the segment's rows of a per-lane partial (lanes l31 / l31 + 32 of WM waves hold one column)
-    auto colsum2 = [&](float (&a)[TN], float (&b)[TN]) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            a[j] += __shfl_xor(a[j], 32, 64);
-            b[j] += __shfl_xor(b[j], 32, 64);
-            if (half == 0) {
-                red[(0 * WM + wm) * C::BN + wn * WC + 32 * j + l31] = a[j];
-                red[(1 * WM + wm) * C::BN + wn * WC + 32 * j + l31] = b[j];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float x = 0.f, y = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                x += red[(0 * WM + w) * C::BN + wn * WC + 32 * j + l31];
-                y += red[(1 * WM + w) * C::BN + wn * WC + 32 * j + l31];
-            }
-            a[j] = x; b[j] = y;
-        }
-        __syncthreads();
-    };
-
-    float cmean[TN], crstd[TN], cgam[TN], cbet[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int64_t col = n0 + wn * WC + 32 * j + l31;
-        cgam[j] = e.gamma[col];
-        cbet[j] = e.beta[col];
-    }
-    if (EPI == EPI_BN_FWD) {
-        float s1[TN], s2[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + wn * WC + 32 * j + l31;
-            const float bv = g.bias ? g.bias[col] : 0.f;
-            s1[j] = 0.f; s2[j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowof(i, r);
-                    float u = g.alpha * acc[i][j][r] + bv;
-                    if (e.res && row < n) u += e.res[(m0 + row) * ldc + col];
-                    acc[i][j][r] = u;
-                    if (row < n) s1[j] += u;
-                }
-        }
-        colsum2(s1, s2);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            cmean[j] = s1[j] * inv_n;
-            s1[j] = 0.f; s2[j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (rowof(i, r) < n) {
-                        const float dlt = acc[i][j][r] - cmean[j];
-                        s1[j] += dlt * dlt;
-                    }
-        }
-        colsum2(s1, s2);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            crstd[j] = rsqrtf(s1[j] * inv_n + e.eps);
-            const int cl = wn * WC + 32 * j + l31;
-            if (wm == 0 && half == 0) {
-                e.mean[(int64_t)seg * g.N + n0 + cl] = cmean[j];
-                e.rstd[(int64_t)seg * g.N + n0 + cl] = crstd[j];
-                colp[0 * C::BN + cl] = cmean[j];
-                colp[1 * C::BN + cl] = crstd[j];
-                colp[2 * C::BN + cl] = cgam[j];
-                colp[3 * C::BN + cl] = cbet[j];
-            }
-        }
-    } else {
-        float s1[TN], s2[TN];
-        float xh[TM][TN][16];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + wn * WC + 32 * j + l31;
-            cmean[j] = e.mean[(int64_t)seg * g.N + col];
-            crstd[j] = e.rstd[(int64_t)seg * g.N + col];
-            s1[j] = 0.f; s2[j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowof(i, r);
-                    float ga = 0.f, h = 0.f;
-                    if (row < n) {
-                        h = (e.z[(m0 + row) * ldc + col] - cmean[j]) * crstd[j];
-                        const float gate = e.relu ? (fmaf(cgam[j], h, cbet[j]) > 0.f ? 1.f : 0.f) : 1.f;
-                        ga = acc[i][j][r] * gate;
-                        s1[j] += ga;
-                        s2[j] += ga * h;
-                    }
-                    acc[i][j][r] = ga;
-                    xh[i][j][r] = h;
-                }
-        }
-        colsum2(s1, s2);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = wn * WC + 32 * j + l31;
-            if (wm == 0 && half == 0) {
-                e.segsum[((int64_t)seg * 2) * g.N + n0 + cl] = s1[j];
-                e.segsum[((int64_t)seg * 2 + 1) * g.N + n0 + cl] = s2[j];
-            }
-            const float k = cgam[j] * crstd[j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][j][r] = k * (acc[i][j][r] - s1[j] * inv_n - xh[i][j][r] * s2[j] * inv_n);
-        }
-    }
-
-    // ---- row phase: each wave turns its WR x WC sub-tile through LDS and stores float4 row pieces
-    float* tile = tile_all + wave * (WR * WC);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * WC + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();                                                         // colp (written by the wm == 0 waves) + the tiles
-    constexpr int LR = WC / 4, RPI = 64 / LR;
-    const int c4 = lane % LR, rsub = lane / LR;
-    const int cl = wn * WC + 4 * c4;
-    const int64_t col = n0 + cl;
-    float4 pm, pr, pg, pb;
-    if (EPI == EPI_BN_FWD) {
-        pm = *reinterpret_cast<const float4*>(colp + 0 * C::BN + cl);
-        pr = *reinterpret_cast<const float4*>(colp + 1 * C::BN + cl);
-        pg = *reinterpret_cast<const float4*>(colp + 2 * C::BN + cl);
-        pb = *reinterpret_cast<const float4*>(colp + 3 * C::BN + cl);
-    }
-    const float inv_keep = e.dropout_p > 0.f ? 1.f / (1.f - e.dropout_p) : 1.f;
-#pragma unroll
-    for (int q = 0; q < WR / RPI; ++q) {
-        const int rl = q * RPI + rsub;
-        const int row = wm * WR + rl;
-        if (row >= n) continue;
-        const float4 v = *reinterpret_cast<const float4*>(tile + rl * WC + 4 * c4);
-        const int64_t off = (m0 + row) * ldc + col;
-        if (EPI == EPI_BN_FWD) {
-            *reinterpret_cast<float4*>(e.z + off) = v;
-            float4 y = make_float4(fmaf(pg.x, (v.x - pm.x) * pr.x, pb.x), fmaf(pg.y, (v.y - pm.y) * pr.y, pb.y),
-                                   fmaf(pg.z, (v.z - pm.z) * pr.z, pb.z), fmaf(pg.w, (v.w - pm.w) * pr.w, pb.w));
-            if (e.relu) y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
-            if (e.dropout_p > 0.f) {
-                const float4 d = gmp::dropout_scale4(e.seed, e.stream_id, (uint64_t)(off >> 2), e.dropout_p, inv_keep);
-                y = make_float4(y.x * d.x, y.y * d.y, y.z * d.z, y.w * d.w);
-            }
-            *reinterpret_cast<float4*>(g.C + off) = y;
-        } else {
-            *reinterpret_cast<float4*>(g.C + off) = v;
-        }
-    }
 }
 
 }  // namespace g2

@@ -99,6 +99,7 @@ gmp_bn_config bn_cfg(const gmp_step_desc& d, bool relu, bool dropout, uint32_t s
     c.dropout_p = (dropout && d.training) ? d.dropout_p : 0.f;
     c.seed = d.seed;
     c.stream_id = site;
+    c.seed_dev = nullptr;
     return c;
 }
 
@@ -578,12 +579,6 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // runs on aux at the start of aux's layer l-1 work -- the flag aux waits for there is set after main's aggregation backward
     // of layer l -- from a rowdot buffer per layer; layer 0's goes to aux's tail.
     const bool eps_on_aux = lean && defer && aux != main;
-    // short segments, training: the inner BatchNorm's backward rides in the epilogue of the input-gradient GEMM above it
-    // (gmp_linear_bn_bwd_input); it leaves the per-segment sums where gmp_bn_param_grads looks for them, so it needs the split form,
-    // and it writes g_z1 one launch earlier than the separate kernels do, so it needs the per-layer g_z1 buffers
-    // OFF by default: measured in the step it does not pay (1.70 against 1.67 ms, profiles/README.md round 2) -- GMP_FUSED_BN_BWD=1
-    static const bool fused_bwd_on = getenv("GMP_FUSED_BN_BWD") && getenv("GMP_FUSED_BN_BWD")[0] == '1';
-    const bool fused_bwd = fused_bwd_on && d.training && split_pg && per_layer && gmp_linear_bn_supported(d.S, d.max_seg, H, 2 * H);
     float *gcur = d.gA, *ga = d.ga;
     for (int l = GMP_STEP_LAYERS - 1; l >= 0; --l) {
         const gmp_layer_desc& L = d.layer[l];
@@ -595,13 +590,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_bn_bwd(gcur, L.z2, d.h[l], d.seg_ptr, nullptr, d.S, d.max_seg, N, H, d.flat + L.off_g2, d.flat + L.off_be2, L.rm2, L.rv2, L.m2, L.s2, gu,
                            tg, tg, d.task_seg, L.tg_g2, L.tg_be2, split_pg ? 0 : T, &c, slice(1 + 2 * l), slice_bytes, main_));
         signal_by_gemm(F_BWD_MA + 2 * l, e[0], main);            // g_u ready: the input-gradient GEMM below tells aux as it starts
-        if (fused_bwd) {      // g_u W2 and the inner BatchNorm's backward in one launch (segment tiles: the sums are in the accumulators)
-            c = bn_cfg(d, true, false, 0);
-            GMP_TRY(gmp_linear_bn_bwd_input(gu, d.flat + L.off_w2, L.z1, d.seg_ptr, d.S, d.max_seg, N, H, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1,
-                                            L.m1, L.s1, gz1, slice(2 + 2 * l), slice_bytes, &c, main_));
-        } else {
-            GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
-        }
+        GMP_TRY(gemm(GMP_GEMM_NN, gu, d.flat + L.off_w2, nullptr, d.gW, N, 2 * H, H, H, 2 * H, 2 * H, false, main_));
         GMP_TRY(signal_flush(F_BWD_MA + 2 * l, main));
         GMP_TRY(await(F_BWD_MA + 2 * l, e[0], aux));
         if (eps_on_aux && l + 1 < GMP_STEP_LAYERS) {
@@ -614,9 +603,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (!lean) (void)hipEventRecord(e[1], aux);      // (a record costs its stream ~3 us: only where somebody waits for it)
         if (!per_layer && l + 2 < GMP_STEP_LAYERS) (void)hipStreamWaitEvent(main, evl[4 * (l + 2) + 3], 0);   // dW1 of layer l+2 has read this g_z1 copy
         c = bn_cfg(d, true, false, 0);
-        if (!fused_bwd)
-            GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
-                               L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
+        GMP_TRY(gmp_bn_bwd(d.gW, L.z1, nullptr, d.seg_ptr, nullptr, d.S, d.max_seg, N, 2 * H, d.flat + L.off_g1, d.flat + L.off_be1, L.rm1, L.rv1, L.m1,
+                           L.s1, gz1, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, split_pg ? 0 : T, &c, slice(2 + 2 * l), slice_bytes, main_));
         signal_by_gemm(F_BWD_MA + 2 * l + 1, e[2], main);        // g_z1 ready
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(signal_flush(F_BWD_MA + 2 * l + 1, main));

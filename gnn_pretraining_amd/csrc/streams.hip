@@ -116,3 +116,13 @@ extern "C" int gmp_streams_share_queue(gmp_stream_t a_, gmp_stream_t b_, int* sh
     if (rc == GMP_OK) *share = tb > 0.5f * ta ? 1 : 0;
     return rc;
 }
+
+// *word += inc, by one thread, in stream order: the per-replay dropout seed of a captured step (gmp_bn_config.seed_dev)
+namespace {
+__global__ void counter_add_kernel(uint64_t* word, uint64_t inc) { *word += inc; }
+}  // namespace
+extern "C" int gmp_counter_add(uint64_t* word, uint64_t inc, gmp_stream_t stream) {
+    if (!word) return gmp::fail(GMP_ERR_ARG, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, word, inc);
+    return gmp::check_launch("counter_add_kernel");
+}

@@ -10,7 +10,14 @@ the encoder's K = 1,433 is padded to 1,440 (a multiple of the GEMM's 32-deep K-s
 the optimizer is the pre-training engine's multi-tensor AdamW over one flat buffer.
 
 `FinetuneGNN` stays the owner of the parameters (its tensors become views into the flat buffer, `state_dict()` keys unchanged),
-so checkpoints, evaluation and the reference-shaped loop around it are untouched."""
+so checkpoints, evaluation and the reference-shaped loop around it are untouched.
+
+Round 3: shapes, pointers and the training rows are the same every step, so the whole step is captured ONCE in a hipGraph
+(torch.cuda.CUDAGraph over the ctypes launches) and replayed: ~65 ctypes crossings + launches per step (1.35 ms, host-bound) become
+one replay.  What changed per step -- the dropout seed -- is read from a device word the graph's last node increments
+(gmp_bn_config.seed_dev, gmp_counter_add), so replay k draws exactly the masks the eager step k draws (tests/test_gpu_modules.py).
+Inside the capture the weight-gradient GEMMs go to a second stream (a parallel branch of the graph; per-layer gradient buffers so the
+input-gradient chain never waits for them), and the encoder GEMM (172 output tiles for 256 CUs) runs as three K-slices."""
 from __future__ import annotations
 
 import ctypes as C
@@ -55,7 +62,15 @@ class NodeClassificationEngine:
         self.stat = {k: f(Lr, c) for k, c in (("m1", 2 * H), ("s1", 2 * H), ("m2", H), ("s2", H))}
         self.enc_mean, self.enc_rstd = f(H), f(H)
         self.logits, self.gA, self.gB, self.ga, self.gW, self.gW2 = f(N, self.classes), f(N, H), f(N, H), f(N, H), f(N, 2 * H), f(N, 2 * H)
-        self.rowdot = f(N)
+        # per-layer g_u / g_z1 (+ one g_u for the encoder): the weight-gradient GEMMs read them on the side stream while the chain moves on
+        self.gu_l, self.gz1_l = [f(N, H) for _ in range(Lr + 1)], [f(N, 2 * H) for _ in range(Lr)]
+        self.rowdot = f(Lr, N)
+        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.side_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+        self.seed_word = torch.zeros(1, dtype=torch.int64, device=dev)        # device copy of step_count for captured steps (gmp_bn_config.seed_dev)
+        import os as _os
+        self.use_graph = dev.type == "cuda" and _os.environ.get("GMP_FINETUNE_GRAPH", "1") != "0"
+        self._graph, self._graph_key, self._graph_step, self._graph_seen = None, None, -1, None
         self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
@@ -117,25 +132,33 @@ class NodeClassificationEngine:
             L.check(rc, what)
 
     def _cfg(self, relu: bool, dropout: bool, site: int) -> L.BnConfig:
+        """Dropout seed of a launch = seed * 1000003 + step number; in a captured step the step number comes from the device word."""
         p = self.dropout_p if (dropout and self.model.training) else 0.0
-        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (self.seed * 1000003 + self.step_count) & (2 ** 64 - 1), site)
+        base = self.seed * 1000003
+        if self._seed_dev:
+            return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, base & (2 ** 64 - 1), site, self._seed_dev)
+        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (base + self.step_count) & (2 ** 64 - 1), site, None)
 
-    def _gemm(self, st, mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc):
-        self._chk(self.lib.gmp_gemm_f32(mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, 1.0, 0, 0, None, 0, st), "gemm")
+    _seed_dev = None
 
-    def _wgrad(self, st, G, X, w_name: str, b_name: str, M_tn: int, N_out: int, ldx: int):
+    def _gemm(self, st, mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, ws: Optional[Tensor] = None):
+        self._chk(self.lib.gmp_gemm_f32(mode, A, B, bias, Cc, M, N, K, lda, ldb, ldc, 1.0, 0, 0, None if ws is None else ws.data_ptr(),
+                                        0 if ws is None else ws.numel(), st), "gemm")
+
+    def _wgrad(self, st, G, X, w_name: str, b_name: str, M_tn: int, N_out: int, ldx: int, ws: Optional[Tensor] = None):
         """dW = G^T X and db = colsum(G) over all rows (one group), straight into the gradient buffer."""
-        g = self.grad.data_ptr()
+        g, ws = self.grad.data_ptr(), (self.gemm_ws if ws is None else ws)
         self._chk(self.lib.gmp_gemm_f32_grouped(TN, G, X, None, g, 1, _i32([0, self.N]), None, None, _i64([self._G(w_name)]), g, _i64([self._G(b_name)]),
-                                                M_tn, N_out, 0, M_tn, ldx, N_out, 1.0, 0, 0, self.gemm_ws.data_ptr(), self.gemm_ws.numel(), st), "wgrad")
+                                                M_tn, N_out, 0, M_tn, ldx, N_out, 1.0, 0, 0, ws.data_ptr(), ws.numel(), st), "wgrad")
 
     # ------------------------------------------------------------------ forward (finetune_model.py:68-80, message passing on the full graph)
     def forward(self) -> Tensor:
         lib, N, P, c = self.lib, self.N, self._P, self.csr
         st = torch.cuda.current_stream(self.device).cuda_stream
         enc, sp = self.model.input_encoder, self.seg_ptr.data_ptr()
+        # 2,708 x 1,440 -> 256 is 172 output tiles for 256 CUs: with a workspace the GEMM runs as K-slices (gmp_gemm_f32_workspace_bytes: 3)
         self._gemm(st, NT, self.x.data_ptr(), P("input_encoder.linear.weight"), P("input_encoder.linear.bias"), self.z0.data_ptr(), N, H, self.dpad,
-                   self.dpad, self.dpad, H)
+                   self.dpad, self.dpad, H, ws=self.gemm_ws)
         cfg = self._cfg(True, True, 1)
         self._chk(lib.gmp_bn_fwd(self.z0.data_ptr(), None, sp, None, 1, N, N, H, P("input_encoder.batch_norm.weight"), P("input_encoder.batch_norm.bias"),
                                  enc.batch_norm.running_mean.data_ptr(), enc.batch_norm.running_var.data_ptr(), self.enc_mean.data_ptr(),
@@ -168,9 +191,57 @@ class NodeClassificationEngine:
 
     # ------------------------------------------------------------------ one optimisation step (finetune.py:162-179 + 318-320)
     def step(self, node_indices: Tensor, targets: Tensor, apply_update: bool = True) -> None:
-        """loss = cross_entropy(model(data)[node_indices], targets) (mean); backward; AdamW.  Nothing is read back: loss()."""
+        """loss = cross_entropy(model(data)[node_indices], targets) (mean); backward; AdamW.  Nothing is read back: loss().
+        Training steps with an update are replayed from a hipGraph captured at the first such call for these index tensors."""
+        if not (self.use_graph and apply_update and self.model.training):
+            self._enqueue(node_indices, targets, apply_update)
+            self.step_count += 1
+            return
+        key = (node_indices.data_ptr(), targets.data_ptr(), int(node_indices.numel()))
+        if self._graph_key != key:
+            # an eager step first (it IS this call's step): code objects loaded, LDS attributes set, row buffers allocated -- nothing of
+            # that may happen inside a capture.  The capture itself (tens of ms) waits for the SECOND call with the same index tensors:
+            # a caller that builds fresh tensors per call never pays for it.
+            self._enqueue(node_indices, targets, True)
+            self.step_count += 1
+            if self._graph_seen != key:
+                self._graph_seen, self._graph_keep = key, (node_indices, targets)
+                return
+            main = torch.cuda.current_stream(self.device)
+            main.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            self._seed_dev = self.seed_word.data_ptr()
+            try:
+                with torch.cuda.graph(graph):
+                    self._enqueue(node_indices, targets, True, forked=True)
+                    self._chk(self.lib.gmp_counter_add(self.seed_word.data_ptr(), 1, torch.cuda.current_stream(self.device).cuda_stream), "seed word")
+            finally:
+                self._seed_dev = None
+            self._bn_calls -= 1                                     # (forward() counted the capture pass, which ran nothing)
+            self._graph, self._graph_key, self._graph_step = graph, key, -1
+            self._graph_keep = (node_indices, targets)             # the captured launches hold these pointers
+            return
+        if self._graph_step != self.step_count:                    # eager steps ran in between (evaluation does not count): resynchronise
+            self.seed_word.fill_(self.step_count)
+        self._graph.replay()
+        self.step_count += 1
+        self._graph_step = self.step_count
+        self._bn_calls += 1
+
+    def _enqueue(self, node_indices: Tensor, targets: Tensor, apply_update: bool, forked: bool = False) -> None:
+        """The step's launches on the current stream.  forked: the weight-gradient GEMMs (they only feed the gradient buffer) go to the
+        side stream behind an event of the main one -- inside a capture a parallel branch of the graph -- and are joined before AdamW."""
         lib, N, P, c, Cn = self.lib, self.N, self._P, self.csr, self.classes
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        main = torch.cuda.current_stream(self.device)
+        st = main.cuda_stream
+        side = self.side if (forked and self.side is not None) else None
+        sst = side.cuda_stream if side is not None else st
+        wws = self.side_ws if side is not None else self.gemm_ws
+
+        def fork() -> None:                                         # the side stream may read what main has produced so far
+            if side is not None:
+                side.wait_stream(main)
+
         self.forward()
         M = int(node_indices.numel())
         if self._train_idx is None or self._train_idx.numel() != M:
@@ -190,42 +261,50 @@ class NodeClassificationEngine:
                                            _i64([self._G("classification_head.mlp.0.weight")]), g, _i64([self._G("classification_head.mlp.0.bias")]),
                                            Cn, H, 0, Cn, H, H, 1.0, 0, 0, None, 0, st), "head wgrad")
         self._gemm(st, NN, self._rows_g.data_ptr(), P("classification_head.mlp.0.weight"), None, self._rows_gh.data_ptr(), M, H, Cn, Cn, H, H)
-        gcur, gu, ga = self.gA, self.gB, self.ga
+        gcur, ga = self.gA, self.ga
         gcur.zero_()
         self._chk(lib.gmp_row_fill(gcur.data_ptr(), idx, self._rows_gh.data_ptr(), M, N, H, 0, st), "scatter g_h")
         sp, one = self.seg_ptr.data_ptr(), _i32([0, 1])
         for l in reversed(range(GNN_NUM_LAYERS)):
             pre, layer = f"gnn_backbone.layers.{l}.", self.model.gnn_backbone.layers[l]
+            gu, gz1 = self.gu_l[l], self.gz1_l[l]
             bn2, cfg = layer.batch_norm, self._cfg(True, True, 10 + l)
             self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z2[l].data_ptr(), self.h[l].data_ptr(), sp, None, 1, N, N, H, P(pre + "batch_norm.weight"),
                                      P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), self.stat["m2"][l].data_ptr(),
                                      self.stat["s2"][l].data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G(pre + "batch_norm.weight")]),
                                      _i64([self._G(pre + "batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2 bwd")
-            self._wgrad(st, gu.data_ptr(), self.r1[l].data_ptr(), pre + "gin_conv.nn.3.weight", pre + "gin_conv.nn.3.bias", H, 2 * H, 2 * H)
+            fork()
+            self._wgrad(sst, gu.data_ptr(), self.r1[l].data_ptr(), pre + "gin_conv.nn.3.weight", pre + "gin_conv.nn.3.bias", H, 2 * H, 2 * H, wws)
             self._gemm(st, NN, gu.data_ptr(), P(pre + "gin_conv.nn.3.weight"), None, self.gW.data_ptr(), N, 2 * H, H, H, 2 * H, 2 * H)
             bn1, cfg = layer.gin_conv.nn[1], self._cfg(True, False, 0)
             self._chk(lib.gmp_bn_bwd(self.gW.data_ptr(), self.z1[l].data_ptr(), None, sp, None, 1, N, N, 2 * H, P(pre + "gin_conv.nn.1.weight"),
                                      P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), self.stat["m1"][l].data_ptr(),
-                                     self.stat["s1"][l].data_ptr(), self.gW2.data_ptr(), g, g, one, _i64([self._G(pre + "gin_conv.nn.1.weight")]),
+                                     self.stat["s1"][l].data_ptr(), gz1.data_ptr(), g, g, one, _i64([self._G(pre + "gin_conv.nn.1.weight")]),
                                      _i64([self._G(pre + "gin_conv.nn.1.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1 bwd")
-            self._wgrad(st, self.gW2.data_ptr(), self.a[l].data_ptr(), pre + "gin_conv.nn.0.weight", pre + "gin_conv.nn.0.bias", 2 * H, H, H)
-            self._gemm(st, NN, self.gW2.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
+            fork()
+            self._wgrad(sst, gz1.data_ptr(), self.a[l].data_ptr(), pre + "gin_conv.nn.0.weight", pre + "gin_conv.nn.0.bias", 2 * H, H, H, wws)
+            self._gemm(st, NN, gz1.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
+            rowdot = self.rowdot[l]
             self._chk(lib.gmp_gin_aggregate_bwd_ex(ga.data_ptr(), c.rowptr_t.data_ptr(), c.col_t.data_ptr(), P(pre + "gin_conv.eps"), self.h[l].data_ptr(),
-                                                   gu.data_ptr(), gcur.data_ptr(), self.rowdot.data_ptr(), N, H, st), "aggregate bwd")
-            self._chk(lib.gmp_group_sum_1d(self.rowdot.data_ptr(), 1, _i32([0, N]), _i64([self._G(pre + "gin_conv.eps")]), g, st), "eps grad")
+                                                   gu.data_ptr(), gcur.data_ptr(), rowdot.data_ptr(), N, H, st), "aggregate bwd")
+            if side is not None:
+                fork()
+            self._chk(lib.gmp_group_sum_1d(rowdot.data_ptr(), 1, _i32([0, N]), _i64([self._G(pre + "gin_conv.eps")]), g, sst), "eps grad")
         enc, cfg = self.model.input_encoder, self._cfg(True, True, 1)
+        gu = self.gu_l[GNN_NUM_LAYERS]
         self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z0.data_ptr(), None, sp, None, 1, N, N, H, P("input_encoder.batch_norm.weight"),
                                  P("input_encoder.batch_norm.bias"), enc.batch_norm.running_mean.data_ptr(), enc.batch_norm.running_var.data_ptr(),
                                  self.enc_mean.data_ptr(), self.enc_rstd.data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G("input_encoder.batch_norm.weight")]),
                                  _i64([self._G("input_encoder.batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn encoder bwd")
         self._wgrad(st, gu.data_ptr(), self.x.data_ptr(), "input_encoder.linear.weight", "input_encoder.linear.bias", H, self.dpad, self.dpad)
+        if side is not None:
+            main.wait_stream(side)                                  # every weight gradient is in the buffer
         # AdamW over the flat buffer (the pre-training engine's multi-tensor kernels with one task: no projection, no clipping)
         self._chk(lib.gmp_mt_pcgrad_clip_adamw(g, self.P, 1, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(), _i32([0]), 1, 0, -1,
                                                self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                                self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, 0.0,
                                                self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(),
                                                self.mt_ws.data_ptr(), self.mt_ws.numel(), int(apply_update), st), "adamw")
-        self.step_count += 1
 
     def loss(self) -> float:
         return float(self.loss_sum.item()) / max(self.num_targets, 1)

@@ -264,42 +264,6 @@ def bn_bwd(g_y: Tensor, x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, 
     return g_u, gg, gb
 
 
-def linear_bn_supported(num_segments: int, max_seg_rows: int, in_features: int, out_features: int) -> bool:
-    return bool(L.lib().gmp_linear_bn_supported(num_segments, max_seg_rows, in_features, out_features))
-
-
-def linear_bn_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor], seg_ptr: Tensor, max_seg_rows: int,
-                  gamma: Tensor, beta: Tensor, cfg: L.BnConfig):
-    """Linear + segment BatchNorm (+ residual, ReLU, dropout) in one launch (gmp_linear_bn_fwd).  Returns (y, u, save_mean, save_rstd):
-    u = x W^T + b (+ residual) is the BatchNorm's input (gnn.py:27-45)."""
-    _need(x, torch.float32, "x", 2); _need(weight, torch.float32, "weight", 2)
-    rows, K = x.shape
-    N = weight.size(0)
-    S = seg_ptr.numel() - 1
-    u = torch.empty(rows, N, dtype=torch.float32, device=x.device)
-    y = torch.empty_like(u)
-    sm = torch.empty(S, N, dtype=torch.float32, device=x.device)
-    sr = torch.empty_like(sm)
-    L.check(L.lib().gmp_linear_bn_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(residual), _ptr(seg_ptr), S, max_seg_rows, rows, K, N, _ptr(gamma),
-                                      _ptr(beta), _ptr(sm), _ptr(sr), _ptr(u), _ptr(y), C.byref(cfg), _stream(x)), "gmp_linear_bn_fwd")
-    return y, u, sm, sr
-
-
-def linear_bn_bwd_input(g_out: Tensor, weight: Tensor, x: Tensor, seg_ptr: Tensor, max_seg_rows: int, gamma: Tensor, beta: Tensor,
-                        save_mean: Tensor, save_rstd: Tensor, cfg: L.BnConfig):
-    """(g_out @ weight) pushed through the BatchNorm (+ ReLU gate) whose input was x, in one launch (gmp_linear_bn_bwd_input).
-    Returns (g_x, segment_sums [S, 2, C])."""
-    rows, K = g_out.shape
-    Cc = weight.size(1)
-    S = seg_ptr.numel() - 1
-    g_x = torch.empty(rows, Cc, dtype=torch.float32, device=x.device)
-    ws = torch.empty(S, 2, Cc, dtype=torch.float32, device=x.device)
-    L.check(L.lib().gmp_linear_bn_bwd_input(_ptr(g_out), _ptr(weight), _ptr(x), _ptr(seg_ptr), S, max_seg_rows, rows, K, Cc, _ptr(gamma), _ptr(beta),
-                                            _ptr(save_mean), _ptr(save_rstd), _ptr(g_x), _ptr(ws), ws.numel() * 4, C.byref(cfg), _stream(x)),
-            "gmp_linear_bn_bwd_input")
-    return g_x, ws
-
-
 def lp_edge_features_fwd(h: Tensor, edges: Tensor) -> Tensor:
     F = _feat_ok(h, "h")
     _need(edges, torch.int64, "edges", 2)

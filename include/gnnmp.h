@@ -188,6 +188,8 @@ typedef struct {
     float dropout_p;     /* 0 = none */
     uint64_t seed;       /* dropout seed */
     uint32_t stream_id;  /* distinct per dropout site */
+    const uint64_t* seed_dev;  /* NULL, or a DEVICE word added to `seed` when the kernel runs: a launch captured in a hipGraph draws fresh
+                                  masks on every replay (the caller bumps the word between replays, gmp_counter_add) */
 } gmp_bn_config;
 
 size_t gmp_bn_workspace_bytes(int64_t rows, int channels, int num_segments, int64_t max_seg_rows);
@@ -228,30 +230,6 @@ int gmp_bn_bwd(const float* g_y, const float* x, const float* residual, const in
 int gmp_bn_param_grads(const void* bwd_workspace, int num_segments, int channels, float* g_gamma, float* g_beta,
                        const int32_t* grp_seg_ptr_host, const int64_t* grp_off_gamma_host, const int64_t* grp_off_beta_host,
                        int num_groups, gmp_stream_t stream);
-
-/* ------------------------------------------------------------------------- *
- * Linear + BatchNorm1d of SHORT segments in one launch (training mode): the two Linear -> BatchNorm pairs of a GINLayer
- * (src/models/gnn.py:27-45: nn.Sequential(Linear, BatchNorm1d, ReLU, Linear) inside GINConv, then `+ h`, BatchNorm1d, ReLU,
- * dropout).  A workgroup's output tile covers every row of one segment, so the batch statistics come out of the GEMM's own
- * accumulators and the separate gmp_bn_fwd / gmp_bn_bwd launch (one more read and write of the activation) goes away.
- *   gmp_linear_bn_supported: 1 when the shape is covered (segments of at most 320 rows with >= 160 (segment, 64-column) tiles,
- *     else at most 384 rows; in_features a multiple of 32, out_features of 32) -- otherwise call gmp_gemm_f32 + gmp_bn_fwd.
- *   gmp_linear_bn_fwd: u = x W^T + bias (+ residual) -> `u` [rows, out] (what gmp_bn_bwd wants as its x, with residual NULL);
- *     y = dropout(relu(BN_segment(u))) -> `y`; batch mean / rstd -> save_mean / save_rstd [S, out].  Same arithmetic per element
- *     as gmp_gemm_f32 followed by gmp_bn_fwd (u bit-identical; the column sums associate differently).
- *   gmp_linear_bn_bwd_input: g = g_out W (the gradient at the OUTPUT of the BatchNorm below the Linear whose weight [out_features,
- *     channels] is given), pushed through that BatchNorm (+ ReLU gate; no dropout) in the epilogue: g_x [rows, channels] is the
- *     gradient at the BatchNorm's input x; the per-segment sums (sum g, sum g * xhat) are left at the start of bn_bwd_workspace
- *     exactly as gmp_bn_bwd with num_groups = 0 leaves them (gmp_bn_param_grads turns them into gamma / beta gradients). */
-int gmp_linear_bn_supported(int num_segments, int64_t max_seg_rows, int in_features, int out_features);
-int gmp_linear_bn_fwd(const float* x, const float* weight, const float* bias, const float* residual, const int32_t* seg_ptr,
-                      int num_segments, int64_t max_seg_rows, int64_t rows, int in_features, int out_features,
-                      const float* gamma, const float* beta, float* save_mean, float* save_rstd, float* u, float* y,
-                      const gmp_bn_config* cfg, gmp_stream_t stream);
-int gmp_linear_bn_bwd_input(const float* g_out, const float* weight, const float* x, const int32_t* seg_ptr, int num_segments,
-                            int64_t max_seg_rows, int64_t rows, int out_features, int channels, const float* gamma,
-                            const float* beta, const float* save_mean, const float* save_rstd, float* g_x,
-                            void* bn_bwd_workspace, size_t workspace_bytes, const gmp_bn_config* cfg, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Link-prediction edge features (the per-edge MLP input, heads.py:58-66):
@@ -436,6 +414,9 @@ int gmp_gate_open(int32_t* flag, int value, gmp_stream_t stream);
  * times out sets *err and lets its stream go on; the engine's data-parallel start-up check (StepEngine.verify_gates) runs
  * its probe steps with a short one so that a stream layout that cannot carry gates shows within seconds. */
 int gmp_gate_set_timeout(double seconds);
+/* *word += inc on the device, in stream order (one thread).  With gmp_bn_config.seed_dev: a step captured in a hipGraph ends with this
+ * launch, so every replay draws the dropout masks of the next step number -- the masks an eager run of that step would draw. */
+int gmp_counter_add(uint64_t* word, uint64_t inc, gmp_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Stacked input encoders (InputEncoder.linear, gnn.py:14,19) for every segment of a step in one

@@ -31,7 +31,7 @@ def _grouped_tn(G, X, rows, out, bias_out, ws):
 
 
 @pytest.mark.parametrize("tile", TILES)
-@pytest.mark.parametrize("M,N,K", [(7392, 512, 256), (6507, 256, 512), (2049, 130, 768), (1025, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(7392, 512, 256), (6507, 256, 512), (2049, 130, 768), (1025, 64, 64), (2708, 256, 1440), (1500, 128, 2048)])
 def test_pipelined_nt_nn_against_fp64(monkeypatch, tile, M, N, K):
     monkeypatch.setenv("GMP_GEMM_PIPE_TILE", tile)
     g = torch.Generator().manual_seed(M + N + K)
@@ -60,6 +60,13 @@ def test_pipelined_gemm_is_exact_on_integer_data(monkeypatch, tile):
     assert torch.equal(ops.gemm(ops.NT, A, W).double(), A.double() @ W.double().t())
     G = torch.randint(-4, 5, (M, N), generator=g).float().to(DEV)
     assert torch.equal(ops.gemm(ops.NN, G, W).double(), G.double() @ W.double())
+    # few output tiles and a long K (the fine-tune encoder's shape class): ops.gemm hands over a workspace and the pipelined kernel runs as
+    # K-slices summed in slice order -- exact on integers whatever the slicing
+    A2 = torch.randint(-3, 4, (1100, 1440), generator=g).float().to(DEV)
+    W2 = torch.randint(-3, 4, (128, 1440), generator=g).float().to(DEV)
+    b2 = torch.randint(-3, 4, (128,), generator=g).float().to(DEV)
+    assert L.lib().gmp_gemm_f32_workspace_bytes(ops.NT, 1100, 128, 1440) > 0
+    assert torch.equal(ops.gemm(ops.NT, A2, W2, b2, relu=True).double(), (A2.double() @ W2.double().t() + b2.double()).clamp_min(0))
     rows = [0, 130, 131, 700, M]                     # a one-row group, ragged tails everywhere
     out, bo = torch.zeros(4, N, K, device=DEV), torch.zeros(4, N, device=DEV)
     _grouped_tn(G, A, rows, out, bo, torch.empty(16 << 20, dtype=torch.uint8, device=DEV))
