@@ -18,6 +18,22 @@ constexpr int COLS = 64;          // columns per block
 constexpr int CQ = COLS / 4;      // float4 column quads per block (16)
 constexpr int RL = THREADS / CQ;  // row lanes per block (16)
 constexpr int SHORT_MAX = 1024;
+// Medium segments (SHORT_MAX < rows <= MID_MAX: the 2,708-node Cora graph is ONE segment): still one read per element, by a 1,024-thread
+// workgroup per (segment, 32 columns) -- 16 columns x 256 row lanes, up to 12 rows per thread in registers.  The chunked long regime took four launches
+// forward and four backward for it (partial / finalize / apply / running: 712 of the fine-tune step's 1,468 us of kernel time, r03 trace).
+constexpr int MID_MAX = 3072, MID_RL = 256, MID_CQ = 4, MID_COLS = 4 * MID_CQ;      // 16-column tiles: at 32 columns x 128 row lanes the tile spilled
+#define GMP_BN_MID_LAUNCH(KERNEL, MAXROWS, S_, C_, ST, ARGS)                                                             \
+    do {                                                                                                                 \
+        const dim3 gridm(S_, (C_) / MID_COLS), blkm(MID_RL * MID_CQ);                                                    \
+        if ((MAXROWS) <= 6 * MID_RL) hipLaunchKernelGGL((KERNEL<6, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);          \
+        else if ((MAXROWS) <= 8 * MID_RL) hipLaunchKernelGGL((KERNEL<8, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);     \
+        else if ((MAXROWS) <= 10 * MID_RL) hipLaunchKernelGGL((KERNEL<10, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);   \
+        else hipLaunchKernelGGL((KERNEL<12, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);                                 \
+    } while (0)
+static bool bn_mid_enabled() {
+    static const bool off = getenv("GMP_BN_MID") && getenv("GMP_BN_MID")[0] == '0';      // A/B aid: 0 = the chunked long regime
+    return !off;
+}
 constexpr int CHUNK = 256;        // rows per chunk in the long regime
 
 struct BnArgs {
@@ -113,24 +129,26 @@ constexpr int SCOLS = 32, SCQ = SCOLS / 4, SRL = THREADS / SCQ;   // 8 quads x 3
 // LDS entries per thread: a 32- or 64-deep chain of dependent reads, twice per BatchNorm forward, on the step's critical path.)
 template <int RL_, int CQ_>
 __device__ __forceinline__ float4 colsum_t(float4 v, float4 (*sh)[CQ_], int rl, int cq) {
-    static_assert(CQ_ == 8 && RL_ % 8 == 0, "layout: 8 column quads x RL_ row lanes, 8 row lanes per wave");
+    constexpr int RPW = 64 / CQ_;                     // row lanes of one wave (8 column quads: 8, 4 column quads: 16)
+    static_assert((CQ_ == 8 || CQ_ == 4) && RL_ % RPW == 0, "layout: CQ_ column quads x RL_ row lanes, 64 / CQ_ row lanes per wave");
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
+    for (int o = CQ_; o < 64; o <<= 1)
         v = make_float4(v.x + __shfl_xor(v.x, o, 64), v.y + __shfl_xor(v.y, o, 64), v.z + __shfl_xor(v.z, o, 64), v.w + __shfl_xor(v.w, o, 64));
     __syncthreads();                                  // (sh may still be read from the previous call)
-    if ((rl & 7) == 0) sh[rl >> 3][cq] = v;
+    if ((rl & (RPW - 1)) == 0) sh[rl / RPW][cq] = v;
     __syncthreads();
     float4 s = sh[0][cq];
 #pragma unroll
-    for (int i = 1; i < RL_ / 8; ++i) s = add4(s, sh[i][cq]);
+    for (int i = 1; i < RL_ / RPW; ++i) s = add4(s, sh[i][cq]);
     return s;
 }
 
 // RL row lanes per column quad: 32 (256 threads, segments up to 16 * 32 = 512 rows) or 64 (512 threads, up to 1,024 rows: the
 // 32-graph segments of the single-domain scheme and of validation batches stay in this one-read regime)
-template <int RPT, int RL = SRL>
-__global__ __launch_bounds__(RL * SCQ) void bn_fwd_short_kernel(BnArgs a) {
-    constexpr int SRL = RL;          // shadows the 32-lane default below
+// CQT column quads per tile: 8 (32 columns) everywhere but the medium regime, which takes 4 (16 columns) x 256 row lanes
+template <int RPT, int RL = SRL, int CQT = SCQ>
+__global__ __launch_bounds__(RL * CQT) void bn_fwd_short_kernel(BnArgs a) {
+    constexpr int SRL = RL, SCQ = CQT, SCOLS = 4 * CQT;          // shadow the 32-lane / 32-column defaults
     __shared__ float4 sh[SRL][SCQ];
     __builtin_amdgcn_s_setprio(3);
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
@@ -313,9 +331,9 @@ __device__ __forceinline__ float4 gate_of(const BnArgs& a, float4 xh, float4 gam
 // Register-resident like the forward, but only the normalised inputs stay in registers (RPT float4): the upstream gradient is
 // read twice (second time out of L2) and the gate is recomputed.  Keeping both operands resident needed 256 VGPRs at
 // RPT = 16 -- one wave per SIMD, nothing to hide a load behind -- and made this the slowest kernel of the backward chain.
-template <int RPT, int RL = SRL>
-__global__ __launch_bounds__(RL * SCQ) void bn_bwd_short_kernel(BnArgs a) {
-    constexpr int SRL = RL;
+template <int RPT, int RL = SRL, int CQT = SCQ>
+__global__ __launch_bounds__(RL * CQT) void bn_bwd_short_kernel(BnArgs a) {
+    constexpr int SRL = RL, SCQ = CQT, SCOLS = 4 * CQT;
     __shared__ float4 sh[SRL][SCQ];
     __builtin_amdgcn_s_setprio(3);
     const int s = blockIdx.x, cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ;
@@ -503,6 +521,8 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
         GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 2) != 0);
+    } else if (max_seg_rows <= MID_MAX && bn_mid_enabled()) {
+        GMP_BN_MID_LAUNCH(bn_fwd_short_kernel, max_seg_rows, S, C, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         if (cfg->training) {
@@ -650,6 +670,8 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
         GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 1) != 0);
+    } else if (max_seg_rows <= MID_MAX && bn_mid_enabled()) {
+        GMP_BN_MID_LAUNCH(bn_bwd_short_kernel, max_seg_rows, S, C, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, blk, 0, st, a);

@@ -16,8 +16,10 @@ Round 3: shapes, pointers and the training rows are the same every step, so the 
 (torch.cuda.CUDAGraph over the ctypes launches) and replayed: ~65 ctypes crossings + launches per step (1.35 ms, host-bound) become
 one replay.  What changed per step -- the dropout seed -- is read from a device word the graph's last node increments
 (gmp_bn_config.seed_dev, gmp_counter_add), so replay k draws exactly the masks the eager step k draws (tests/test_gpu_modules.py).
-Inside the capture the weight-gradient GEMMs go to a second stream (a parallel branch of the graph; per-layer gradient buffers so the
-input-gradient chain never waits for them), and the encoder GEMM (172 output tiles for 256 CUs) runs as three K-slices."""
+The encoder GEMM (172 output tiles for 256 CUs) runs as three K-slices, and the one-segment BatchNorms (2,708 rows) take the medium
+regime of csrc/batchnorm.hip (one launch instead of four).  Measured (MI355X, profiles/README.md round 3): the step was NOT host-bound as
+round 2 believed -- its kernels add up to 1.43 ms (BatchNorm 0.58, GEMMs 0.56) -- so the replay (host 0.76 ms) runs at the GPU's 1.38 ms;
+a parallel graph branch for the weight-gradient GEMMs (GMP_FINETUNE_FORK=1) makes the replay itself cost 1.45 ms of host time."""
 from __future__ import annotations
 
 import ctypes as C
@@ -70,6 +72,10 @@ class NodeClassificationEngine:
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=dev)        # device copy of step_count for captured steps (gmp_bn_config.seed_dev)
         import os as _os
         self.use_graph = dev.type == "cuda" and _os.environ.get("GMP_FINETUNE_GRAPH", "1") != "0"
+        # weight-gradient GEMMs as a parallel branch of the captured graph: measured SLOWER on this runtime (ROCm 7.2) -- replaying a graph
+        # with a second branch costs the host 1.45 ms per replay against 0.76 ms for the single chain (profiles/README.md round 3), and the
+        # step is then host-bound again (1.52 against 1.38 ms) -- so the capture stays on one stream; GMP_FINETUNE_FORK=1 for A/B runs
+        self.fork_wgrads = _os.environ.get("GMP_FINETUNE_FORK", "0") == "1"
         self._graph, self._graph_key, self._graph_step, self._graph_seen = None, None, -1, None
         self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
@@ -213,7 +219,7 @@ class NodeClassificationEngine:
             self._seed_dev = self.seed_word.data_ptr()
             try:
                 with torch.cuda.graph(graph):
-                    self._enqueue(node_indices, targets, True, forked=True)
+                    self._enqueue(node_indices, targets, True, forked=self.fork_wgrads)
                     self._chk(self.lib.gmp_counter_add(self.seed_word.data_ptr(), 1, torch.cuda.current_stream(self.device).cuda_stream), "seed word")
             finally:
                 self._seed_dev = None

@@ -1,0 +1,36 @@
+"""Cora_NC fine-tune step alone (BASELINE.json configs[4]) for rocprofv3 / A-B timing: python scripts/profile_cora.py [steps] [graph|eager|graph1]
+graph1 = captured on one stream (the engine's default), graph = captured with the weight-gradient side branch, eager = launch by launch."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from gnn_pretraining_amd import synthetic as S
+from gnn_pretraining_amd.finetune.engine import NodeClassificationEngine
+from gnn_pretraining_amd.models import FinetuneGNN
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+mode = sys.argv[2] if len(sys.argv) > 2 else "graph1"
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(0)
+torch.manual_seed(0)
+g = S.cora_like(gen)
+model = FinetuneGNN(dev, "Cora_NC", "full_finetune")
+model.train()
+eng = NodeClassificationEngine(model, g.x, g.edge_index, dev, seed=0)
+eng.use_graph = mode != "eager"
+eng.fork_wgrads = mode == "graph"
+idx = torch.randperm(g.num_nodes, generator=gen)[:140].to(dev)
+y = g.y[idx.cpu()].to(dev)
+for _ in range(20):
+    eng.step(idx, y)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    eng.step(idx, y)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"{mode}: {(t2 - t0) / steps * 1e3:.3f} ms/step (host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step), loss {eng.loss():.4f}")

@@ -247,7 +247,7 @@ def _bn_oracle(x, res, seg, gamma, beta, rm, rv, training, relu):
 
 @pytest.mark.parametrize("seg,C,relu,with_res", [([0, 264], 256, True, False), ([0, 40, 300, 301 + 30, 600], 512, True, True),
                                                  ([0, 2708], 256, True, True), ([0, 1500, 1500 + 700], 64, False, False),
-                                                 ([0, 2, 5], 128, True, False)])
+                                                 ([0, 2, 5], 128, True, False), ([0, 3500, 3500 + 1100], 128, True, True)])   # short / medium / chunked regimes
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_fwd_bwd(seg, C, relu, with_res, training):
     gen = torch.Generator().manual_seed(sum(seg) + C)
