@@ -386,10 +386,10 @@ void launch_mode(int mode, const GemmArgs& g, dim3 grid, hipStream_t st, bool fa
 // GMP_GEMM_IMPL=old keeps every problem on gemm_kernel (A/B aid); GMP_GEMM_PIPE_TILE=0..3 forces 128x128 / 64x128 / 128x64 / 64x64.
 constexpr int PIPE_TILES[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
 
-template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
+template <int TM, int TN, bool A_KC, bool B_KC, int STAGES, int BUFS = STAGES>
 int launch_pipe_cfg(const GemmArgs& g, int tiles_m, int tiles_n, int z, hipStream_t st) {
-    using C = g2::Cfg<TM, TN, A_KC, B_KC, STAGES>;
-    auto kern = g2::gemm_pipe_kernel<TM, TN, A_KC, B_KC, STAGES>;
+    using C = g2::Cfg<TM, TN, A_KC, B_KC, STAGES, BUFS>;
+    auto kern = g2::gemm_pipe_kernel<TM, TN, A_KC, B_KC, STAGES, BUFS>;
     // a workgroup may ask for up to 160 KiB of LDS once the function says so -- per DEVICE (the attribute belongs to the device's copy of
     // the function): one bit per device ordinal, set after the call succeeded there; racing threads at worst both make the (idempotent) call
     static std::atomic<uint64_t> attr_set{0};
@@ -403,7 +403,11 @@ int launch_pipe_cfg(const GemmArgs& g, int tiles_m, int tiles_n, int z, hipStrea
 }
 
 // LDS ring depth: 4 stages everywhere (128x128: 4 x 32 KB, one block per CU; 64x64: 4 x 16 KB, two blocks per CU).  A 3-stage 64x64
-// ring (three blocks per CU) is 1 us faster alone and slower inside the step (1.53 against 1.45 ms): GMP_GEMM_PIPE_STAGES=3
+// ring (three blocks per CU) is 1 us faster alone and slower inside the step (1.53 against 1.45 ms): GMP_GEMM_PIPE_STAGES=3.
+// Round 3, GMP_GEMM_PIPE_STAGES=32: the 3-stage schedule on TWO buffers (gemm_pipe.h "early free": 32 KB, four blocks per CU, all 928
+// tiles of a layer GEMM resident at once): 23.2 against 24.6 us alone (83.3 TF/s = 0.53 of the fp32 MFMA peak, NN 82.2), and again slower
+// inside the step (1.416 against 1.401 ms, two interleaved pairs): four resident GEMM blocks per CU crowd out the other streams' kernels,
+// which is what the step's concurrency lives on.  Kept selectable for GEMM-only callers; the step's default stays 4 / 4.
 template <bool A_KC, bool B_KC>
 int launch_pipe_tile(int tile, const GemmArgs& g, int64_t rows, int z, hipStream_t st) {
     const int TMs = PIPE_TILES[tile][0], TNs = PIPE_TILES[tile][1];
@@ -417,7 +421,8 @@ int launch_pipe_tile(int tile, const GemmArgs& g, int64_t rows, int z, hipStream
         case 2: return deep == 3 ? launch_pipe_cfg<2, 1, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
                                  : launch_pipe_cfg<2, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
         default: return deep == 3 ? launch_pipe_cfg<1, 1, A_KC, B_KC, 3>(g, tiles_m, tiles_n, z, st)
-                                  : launch_pipe_cfg<1, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
+                      : deep == 32 ? launch_pipe_cfg<1, 1, A_KC, B_KC, 3, 2>(g, tiles_m, tiles_n, z, st)       // 32 KB: four blocks per CU
+                                   : launch_pipe_cfg<1, 1, A_KC, B_KC, 4>(g, tiles_m, tiles_n, z, st);
     }
 }
 
@@ -434,6 +439,11 @@ int launch_pipe(int mode, int tile, const GemmArgs& g_in, int64_t rows, int z, h
 inline bool pipe_enabled() {
     const char* e = getenv("GMP_GEMM_IMPL");
     return !(e && !strcmp(e, "old"));
+}
+// smallest row count (NT / NN forms) that takes the pipelined kernel (read per call: A/B aid)
+inline int64_t pipe_min_rows() {
+    const char* e = getenv("GMP_GEMM_PIPE_MIN_ROWS");
+    return e ? atoll(e) : 1024;
 }
 inline int pipe_forced_tile() {
     const char* e = getenv("GMP_GEMM_PIPE_TILE");
@@ -518,7 +528,7 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
 #ifdef GMP_PIPE_DEBUG
     if (getenv("GMP_PIPE_NOSTORE")) g.accumulate |= 0x100;
 #endif
-    if (mode != GMP_GEMM_TN && M >= 1024 && N >= 64 && pipe_ok(mode, g) && (g.splitk == 1 || N % 4 == 0)) {   // (slices are stored as float4 rows of N)
+    if (mode != GMP_GEMM_TN && M >= pipe_min_rows() && N >= 64 && pipe_ok(mode, g) && (g.splitk == 1 || N % 4 == 0)) {   // (slices are stored as float4 rows of N)
         if (g.splitk == 1) return launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, 1, st);
         // few output tiles and a long K (the caller handed over a workspace): K-slices of the pipelined kernel, summed in slice order
         if (int rc = launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, g.splitk, st)) return rc;
@@ -641,7 +651,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         g.M = 0;
         static const bool nofast_g2 = getenv("GMP_GEMM_NOFAST") != nullptr;
         g.K = K;
-        if (max_rows >= 1024 && N >= 64 && pipe_ok(mode, g)) return launch_pipe(mode, pipe_pick_tile(max_rows, N, groups), g, max_rows, groups, st);
+        if (max_rows >= pipe_min_rows() && N >= 64 && pipe_ok(mode, g)) return launch_pipe(mode, pipe_pick_tile(max_rows, N, groups), g, max_rows, groups, st);
         launch_mode<64, 64>(mode, g, dim3((unsigned)((N + 63) / 64), (unsigned)((max_rows + 63) / 64), (unsigned)groups), st,
                             !nofast_g2 && fast_ok<BK_DEFAULT>(mode, g, 1));
     }

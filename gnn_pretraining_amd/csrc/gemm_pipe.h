@@ -121,13 +121,21 @@ __device__ __forceinline__ void read_frag(const char* tile, int rb, int g, int l
     }
 }
 
-template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
+// STAGES is the SCHEDULE: K-step s + STAGES - 1 is issued at the hand-over of step s.  BUFS is how many LDS buffers back it: STAGES (the DMA
+// of step s + STAGES - 1 goes to the buffer of step s - 1), or STAGES - 1 ("early free"): at the hand-over every fragment of stage s is in
+// registers already (its last sub-step's reads were issued a sub-step earlier), so after the wave's own lgkmcnt(0) and the barrier the
+// buffer of stage s ITSELF can take the new DMA.  One buffer less per block for the same prefetch distance: a 64 x 64 tile with a
+// 3-stage schedule needs 32 KB instead of 48, and FOUR blocks share a CU -- the 928 tiles of a layer GEMM are resident at once, one
+// round instead of 1.8, one exposed prologue / epilogue instead of two.
+template <int TM, int TN, bool A_KC, bool B_KC, int STAGES, int BUFS = STAGES>
 struct Cfg {
+    static_assert(BUFS == STAGES || BUFS == STAGES - 1, "buffers: one per stage of the schedule, or one less (early free)");
+    static_assert(BUFS >= 2, "at least two buffers");
     static constexpr int BM = 64 * TM, BN = 64 * TN;
     using OA = Operand<BM, A_KC>;
     using OB = Operand<BN, B_KC>;
     static constexpr int STAGE_BYTES = OA::BYTES + OB::BYTES;
-    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int LDS_BYTES = BUFS * STAGE_BYTES;
     static constexpr int LOADS = OA::PER_WAVE + OB::PER_WAVE;      // LDS-DMA instructions per wave per stage
 };
 
@@ -139,7 +147,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Fragments of sub-step g of stage `st` for this wave's TM x TN blocks of 32 rows / columns.
 template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
 __device__ __forceinline__ void read_sub(const char* st, int g, int wm, int wn, int l31, int half, float (&fa)[TM][4], float (&fb)[TN][4]) {
-    using C = Cfg<TM, TN, A_KC, B_KC, STAGES>;
+    using C = Cfg<TM, TN, A_KC, B_KC, STAGES>;          // (only tile geometry is used here: the same for every BUFS)
 #pragma unroll
     for (int i = 0; i < TM; ++i) read_frag<C::BM, A_KC>(st, wm * (C::BM / 2) + 32 * i, g, l31, half, fa[i]);
 #pragma unroll
@@ -175,9 +183,10 @@ __device__ __forceinline__ void sched_sub() {
 #endif
 }
 
-template <int TM, int TN, bool A_KC, bool B_KC, int STAGES>
+template <int TM, int TN, bool A_KC, bool B_KC, int STAGES, int BUFS = STAGES>
 __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
-    using C = Cfg<TM, TN, A_KC, B_KC, STAGES>;
+    using C = Cfg<TM, TN, A_KC, B_KC, STAGES, BUFS>;
+    constexpr bool EARLY = BUFS < STAGES;
     constexpr bool IS_TN = !A_KC && !B_KC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -252,10 +261,10 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
         la.init(g.A, g.lda, m0, Mrows, kbeg, lane, wave);
         lb.init(Bp, g.ldb, n0, g.N, kbeg, lane, wave);
     }
-    auto stage_ptr = [&](int s) -> char* { return smem + (s % STAGES) * C::STAGE_BYTES; };
+    auto stage_ptr = [&](int s) -> char* { return smem + (s % BUFS) * C::STAGE_BYTES; };
     const unsigned lds0 = lds_address(smem);
     auto issue = [&](int s) {          // stage of K-step s; wave-uniform control flow
-        const unsigned sp = lds0 + (s % STAGES) * C::STAGE_BYTES;
+        const unsigned sp = lds0 + (s % BUFS) * C::STAGE_BYTES;
         if (IS_TN && ktail && s == nfull) {
             la.issue_tail(sp, wave, lane, ktail, g.lda);
             lb.issue_tail(sp + C::OA::BYTES, wave, lane, ktail, g.ldb);
@@ -314,8 +323,11 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
         mfma_sub<TM, TN, TAIL>(acc, fa0, fb0, 2, half, klen);
         sched_sub<NREADS, NMFMA>();
         if (s + 1 < nsteps) {
-            if (STAGES >= 4 && s + 2 < nsteps) wait_vmcnt<C::LOADS>();          // 4 buffers: stage s + 2 may stay in flight
+            if (STAGES >= 4 && s + 2 < nsteps) wait_vmcnt<C::LOADS>();          // 4-stage schedule: stage s + 2 may stay in flight
             else wait_vmcnt<0>();
+            // early free: the DMA issued below lands in THIS stage's buffer -- this wave's reads of it (sub-step 3's were issued behind the
+            // first MFMA of sub-step 2) must have returned before any wave may overwrite it; the barrier alone does not wait for them
+            if (EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1);
             read_sub<TM, TN, A_KC, B_KC, STAGES>(stage_ptr(s + 1), 0, wm, wn, l31, half, fa0, fb0);

@@ -333,9 +333,16 @@ def test_engine_s5_step_with_domain_adversarial_term():
     eng.lr.mul_(1000)
     eng.temperature, eng.grl_lambda = temp(), grl()
     o_batches = {d: to_oracle(b) for d, b in host.items()}
-    lo, _, _, _ = OTr.train_step(om, otasks, oopt, obal, grl, temp, o_batches, gen, artifacts=oracle_artefacts(art, host), order=order)
+    # the engine first, then the oracle with the ReLU / sign gates the HIP forward used (oracle/gates.py), as in the s4 step test above:
+    # the UPDATE is compared at the same bar (1e-3; it was 2e-2 while the two sides resolved near-zero gates independently)
+    import oracle.gates as OGt
     eng.step(inp, gen, art=art, order=order)
     got = eng.losses()
+    tapes = engine_gate_tapes(eng, eng.last_plan, art)
+    tape = OGt.GateTape([m for t in tasks for m in tapes[t].masks])
+    with OGt.use_tape(tape):
+        lo, _, _, _ = OTr.train_step(om, otasks, oopt, obal, grl, temp, o_batches, gen, artifacts=oracle_artefacts(art, host), order=order)
+    assert tape.done()
     for n in tasks:
         assert abs(got[n] - lo[n].item()) <= 1e-4 * abs(lo[n].item()), n
     after_o, after_h = om.state_dict(), hm.state_dict()
@@ -345,7 +352,8 @@ def test_engine_s5_step_with_domain_adversarial_term():
     assert "heads.domain_adv.classifier.mlp.0.weight" in moved_o
     num = sum(((after_h[k].cpu() - after_o[k]).double() ** 2).sum().item() for k in moved_o)
     den = sum(((after_o[k] - before[k]).double() ** 2).sum().item() for k in moved_o)
-    assert (num / den) ** 0.5 <= 2e-2, f"relative update error {(num / den) ** 0.5:.3e}"
+    print(f"s5 relative update error {(num / den) ** 0.5:.3e}")
+    assert (num / den) ** 0.5 <= 1e-3, f"relative update error {(num / den) ** 0.5:.3e}"
 
 
 @pytest.mark.parametrize("present,rng_mode,scheme", [(["ENZYMES"], "reference", "s4"), (["PROTEINS"], "vectorized", "s4"),
