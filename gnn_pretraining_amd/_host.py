@@ -26,12 +26,5 @@ def host_cores(cap: int = 16) -> int:
 
 def limit_host_threads(n: int = 1) -> None:
     torch.set_num_threads(max(1, min(n, host_cores())))
-    # Two Python threads share a step: the launcher (upload + one long C call, which releases the GIL) and the prefetcher
-    # (draw + plan of the next step).  With CPython's default 5 ms switch interval the launcher, back from its C call, waits for
-    # the prefetcher to reach a blocking call before it gets the GIL again; GMP_SWITCH_INTERVAL_US sets the interval.
-    # Measured (scripts/diag_dp_overlap.py, host-bound data-parallel mode): 500 / 100 / 30 us gave 1.61 / 1.72-1.88 / 1.86 ms per
-    # step against 1.59-1.67 with the default -- more hand-overs cost more than the waits they save.  Left unset by default.
-    us = os.environ.get("GMP_SWITCH_INTERVAL_US")
-    if us:
-        import sys
-        sys.setswitchinterval(max(float(us), 1.0) * 1e-6)
+    # (CPython's switch interval stays at its default: 500 / 100 / 30 us gave 1.61 / 1.72-1.88 / 1.86 ms per step against 1.59-1.67 with the
+    # default in round 2 -- more hand-overs cost more than the waits they save -- and the GMP_SWITCH_INTERVAL_US switch was removed in round 3.)

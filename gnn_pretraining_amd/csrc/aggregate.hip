@@ -121,77 +121,11 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_kernel(const float4* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Streaming form for inputs that do not fit the caches (the 65,536-graph rung: x = 2.2 GB).
-// What limits the one-wave-per-chunk kernel above at that size is not bandwidth but (a) three dependent
-// memory latencies per row (rowptr -> col -> rows) and (b) no cache reuse: 8192 waves each walking their
-// own distant chunk keep ~270 MB of "current graphs" live, so a neighbour row (wanted ~4.8 times) is usually
-// re-fetched from HBM.  Here a 1024-thread workgroup owns a contiguous span and its 16 waves take ADJACENT
-// rows of a 256-row tile, so the whole CU works inside one or two graphs (~66 KB: L1/L2 resident) and every
-// row of x leaves HBM once; rowptr and col of a tile are staged into LDS with two coalesced block-wide
-// loads, leaving ONE memory latency per row; the output is written with non-temporal stores so it does not
-// evict the x rows waiting to be re-read.
-constexpr int COLCAP = 3072;
-
-template <int SB, int TILE, bool NT_STORE>
-__global__ __launch_bounds__(SB) void gin_aggregate_stream_kernel(const float4* __restrict__ x, const int* __restrict__ rowptr,
-                                                                  const int* __restrict__ col, const float* __restrict__ eps,
-                                                                  float4* __restrict__ out, int64_t nrows, int tiles_per_block) {
-    constexpr int SWAVES = SB / GMP_WAVE;
-    __shared__ int s_ptr[TILE + 1];
-    __shared__ int s_col[COLCAP];
-    const int per_xcd = gridDim.x / NUM_XCD;
-    const int lb = (blockIdx.x % NUM_XCD) * per_xcd + blockIdx.x / NUM_XCD;
-    const int lane = threadIdx.x % GMP_WAVE, wv = threadIdx.x / GMP_WAVE;
-    const float scale = 1.f + (eps ? eps[0] : 0.f);
-    const int64_t ntiles = (nrows + TILE - 1) / TILE;
-    const int64_t t0 = (int64_t)lb * tiles_per_block;
-    for (int64_t t = t0; t < t0 + tiles_per_block && t < ntiles; ++t) {
-        const int64_t r0 = t * TILE;
-        const int nr = (int)(nrows - r0 < TILE ? nrows - r0 : TILE);
-        __syncthreads();                                   // everyone is done with the previous tile's LDS
-        for (int i = threadIdx.x; i <= nr; i += SB) s_ptr[i] = rowptr[r0 + i];
-        __syncthreads();
-        const int base = s_ptr[0], cnt = s_ptr[nr] - base;
-        const bool staged = cnt <= COLCAP;
-        if (staged)
-            for (int i = threadIdx.x; i < cnt; i += SB) s_col[i] = col[base + i];
-        __syncthreads();
-        for (int rr = wv; rr < nr; rr += SWAVES) {
-            const int64_t r = r0 + rr;
-            const int start = s_ptr[rr], end = s_ptr[rr + 1];
-            float4 acc = x[r * 64 + lane];
-            acc = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
-            int e = start;
-            for (; e + 4 <= end; e += 4) {
-                int c0, c1, c2, c3;
-                if (staged) { c0 = s_col[e - base]; c1 = s_col[e - base + 1]; c2 = s_col[e - base + 2]; c3 = s_col[e - base + 3]; }
-                else { c0 = col[e]; c1 = col[e + 1]; c2 = col[e + 2]; c3 = col[e + 3]; }
-                const int64_t u0 = __builtin_amdgcn_readfirstlane(c0), u1 = __builtin_amdgcn_readfirstlane(c1);
-                const int64_t u2 = __builtin_amdgcn_readfirstlane(c2), u3 = __builtin_amdgcn_readfirstlane(c3);
-                const float4 a = x[u0 * 64 + lane], b = x[u1 * 64 + lane], c = x[u2 * 64 + lane], d = x[u3 * 64 + lane];
-                acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
-            }
-            for (; e < end; ++e) {
-                const int cc = staged ? s_col[e - base] : col[e];
-                const int64_t u = __builtin_amdgcn_readfirstlane(cc);
-                acc = f4add(acc, x[u * 64 + lane]);
-            }
-            if (NT_STORE) {
-                float* o = reinterpret_cast<float*>(out + r * 64 + lane);
-                __builtin_nontemporal_store(acc.x, o);
-                __builtin_nontemporal_store(acc.y, o + 1);
-                __builtin_nontemporal_store(acc.z, o + 2);
-                __builtin_nontemporal_store(acc.w, o + 3);
-            } else {
-                out[r * 64 + lane] = acc;
-            }
-        }
-    }
-}
-
-// LDS-resident tile form.  The kernel above leaves every neighbour read to L1/L2: per launch ~4.8 KiB of x rows per
-// output row cross the L2->CU fabric (10.4 GB reads + 2.2 GB writes in 1.1 ms ~ 11.5 TB/s), which is what bounds it,
-// not HBM.  Here a workgroup copies its tile of TILE consecutive rows (TILE KiB) into LDS once -- fully coalesced, one
+// Inputs beyond the caches (the 65,536-graph rung: x = 2.2 GB): the LDS-resident tile form below.  (Its cache-resident predecessor --
+// 1,024-thread workgroups over adjacent rows, rowptr / col staged in LDS, neighbour rows through L1 / L2 -- topped out at 4.0 TB/s on
+// ~11.5 TB/s of L2 -> CU traffic and was removed in round 3 together with its GMP_AGG_VARIANT switch; profiles/README.md round 1 has its numbers.)
+// LDS-resident tile form.  Leaving every neighbour read to L1/L2 moves ~4.8 KiB of x rows per output row across the L2->CU fabric
+// (10.4 GB reads + 2.2 GB writes in 1.1 ms ~ 11.5 TB/s), which is what bounds such a kernel, not HBM.  Here a workgroup copies its tile of TILE consecutive rows (TILE KiB) into LDS once -- fully coalesced, one
 // pass over x -- and neighbour rows that fall inside the tile (almost all: a tile spans ~4 whole graphs, and edges never
 // leave a graph) are read from LDS; only the graphs cut by a tile border reach into global memory.  The next tile's
 // rows / rowptr / col are prefetched into registers while the current tile is being reduced, so HBM stays busy during
@@ -451,55 +385,8 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N < 0 || (N > 0 && (!x || !rowptr || !out))) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd: null pointer");
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
-    if (feat == 256 && N >= 65536) {          // working set beyond the caches: streaming kernel
-        // GMP_AGG_VARIANT (tuning aid): 12 = LDS-resident 144-row tiles, 1024 threads, 1 block/CU (default: 153 KB of the
-        // 160 KB LDS); 5 = 128-row tiles; 6 = 64-row
-        // tiles, 512 threads, 2 blocks/CU; 8 = 5 with plain stores; cache-resident predecessors: 0 = 1024 threads /
-        // 256-row tiles / nt stores, 1 = same with plain stores, 2 = 512-row tiles, 3 = 512 threads / 128-row tiles,
-        // 4 = 512 threads / 256-row tiles.  GMP_AGG_BLOCKS = grid
-        static const int variant = getenv("GMP_AGG_VARIANT") ? atoi(getenv("GMP_AGG_VARIANT")) : 12;
-        static const int blocks_env = getenv("GMP_AGG_BLOCKS") ? atoi(getenv("GMP_AGG_BLOCKS")) : 0;
-        hipStream_t st = (hipStream_t)stream;
-#define GMP_STREAM(SBV, TILEV, NTV, DEFBLOCKS)                                                                        \
-        do {                                                                                                          \
-            const int64_t ntiles = (N + TILEV - 1) / TILEV;                                                           \
-            int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \
-            int tpb = (int)((ntiles + blocks - 1) / blocks);                                                          \
-            hipLaunchKernelGGL((gin_aggregate_stream_kernel<SBV, TILEV, NTV>), dim3(blocks), dim3(SBV), 0, st,        \
-                               (const float4*)x, rowptr, col, eps, (float4*)out, N, tpb);                            \
-        } while (0)
-#define GMP_LDSTILE(SBV, TILEV, CCAPV, NTV, DEFBLOCKS)                                                                      \
-        do {                                                                                                          \
-            auto kern = gin_aggregate_ldstile_kernel<SBV, TILEV, CCAPV, NTV>;                                         \
-            const size_t lds = (size_t)TILEV * 1024 + (size_t)CCAPV * 4 + (size_t)(TILEV + 16) * 4;                   \
-            static std::atomic<uint64_t> attr_set{0};                                                                 \
-            if (!gmp::lds_attr_done(attr_set)) {                                                                      \
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_ldstile: LDS attribute: %s", hipGetErrorString(e)); \
-                gmp::lds_attr_mark(attr_set);                                                                         \
-            }                                                                                                         \
-            const int64_t ntiles = (N + TILEV - 1) / TILEV;                                                           \
-            int blocks = blocks_env > 0 ? blocks_env / NUM_XCD * NUM_XCD : DEFBLOCKS;                                 \
-            int tpb = (int)((ntiles + blocks - 1) / blocks);                                                          \
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(SBV), lds, st, (const float4*)x, rowptr, col, eps,            \
-                               (float4*)out, N, tpb, (const float4*)nullptr, (float*)nullptr);                        \
-        } while (0)
-        switch (variant) {
-            case 5: GMP_LDSTILE(1024, 128, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
-            case 6: GMP_LDSTILE(512, 64, 1024, true, 512); return gmp::check_launch("gin_aggregate_ldstile_kernel");
-            case 12: if (blocks_env <= 0) return launch_ldstile144<false>(x, rowptr, col, eps, out, N, nullptr, nullptr, st);
-                     GMP_LDSTILE(1024, 144, 2048, true, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
-            case 8: GMP_LDSTILE(1024, 128, 2048, false, 256); return gmp::check_launch("gin_aggregate_ldstile_kernel");
-            case 1: GMP_STREAM(1024, 256, false, 512); break;
-            case 2: GMP_STREAM(1024, 512, true, 512); break;
-            case 0: GMP_STREAM(1024, 256, true, 512); break;
-            case 4: GMP_STREAM(512, 256, true, 1024); break;
-            default: GMP_STREAM(512, 128, true, 1024); break;
-        }
-#undef GMP_STREAM
-#undef GMP_LDSTILE
-        return gmp::check_launch("gin_aggregate_stream_kernel");
-    }
+    if (feat == 256 && N >= 65536)            // working set beyond the caches: LDS-resident 144-row tiles (153 KB of the CU's 160 KB), 1,024 threads, one block per CU
+        return launch_ldstile144<false>(x, rowptr, col, eps, out, N, nullptr, nullptr, (hipStream_t)stream);
     Plan p = make_plan(N);
     return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, (hipStream_t)stream, x, rowptr, col, x, eps,
                                                       nullptr, out, nullptr, N, F4);
@@ -537,9 +424,8 @@ extern "C" int gmp_gin_aggregate_bwd(const float* g_out, const int32_t* rowptr_t
         if (g_eps && hipMemsetAsync(g_eps, 0, sizeof(float), st) != hipSuccess) return gmp::fail(GMP_ERR_LAUNCH, "gin_aggregate_bwd: memset");
         return GMP_OK;
     }
-    // beyond the caches (the roofline rung): the forward's LDS-resident-tile kernel on the transposed CSR (GMP_AGG_BWD_TILE=0: off)
-    static const bool tile_bwd = !(getenv("GMP_AGG_BWD_TILE") && atoi(getenv("GMP_AGG_BWD_TILE")) == 0);
-    if (feat == 256 && N >= 65536 && tile_bwd && col_t) {
+    // beyond the caches (the roofline rung): the forward's LDS-resident-tile kernel on the transposed CSR
+    if (feat == 256 && N >= 65536 && col_t) {
         if (!g_eps) return launch_ldstile144<false>(g_out, rowptr_t, col_t, eps, g_x, N, nullptr, nullptr, st);
         if (ws_bytes < gmp_gin_aggregate_bwd_workspace_bytes(N, feat)) return gmp::fail(GMP_ERR_WORKSPACE, "gin_aggregate_bwd: workspace");
         float* rowdot = (float*)ws;

@@ -30,10 +30,6 @@ constexpr int MID_MAX = 3072, MID_RL = 256, MID_CQ = 4, MID_COLS = 4 * MID_CQ;  
         else if ((MAXROWS) <= 10 * MID_RL) hipLaunchKernelGGL((KERNEL<10, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);   \
         else hipLaunchKernelGGL((KERNEL<12, MID_RL, MID_CQ>), gridm, blkm, 0, ST, ARGS);                                 \
     } while (0)
-static bool bn_mid_enabled() {
-    static const bool off = getenv("GMP_BN_MID") && getenv("GMP_BN_MID")[0] == '0';      // A/B aid: 0 = the chunked long regime
-    return !off;
-}
 constexpr int CHUNK = 256;        // rows per chunk in the long regime
 
 struct BnArgs {
@@ -481,8 +477,7 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
 // at 16 rows per thread needs 204 VGPRs: beside the resident blocks of the weight-gradient GEMM it runs next to in the step
 // (4 waves x 60 VGPRs per SIMD) only ONE such wave fits per SIMD, half the workgroups wait for a slot and the kernel takes
 // 31 us instead of the 15 us it takes alone; at 8 rows per thread two waves fit.  The forward takes the wide form too since the
-// column sums fold by shuffles (1.420 -> 1.405 ms per step; 1,024-thread blocks: no further gain).  GMP_BN_WIDE = bit 0 backward,
-// bit 1 forward (A/B aid; default 3).
+// column sums fold by shuffles (1.420 -> 1.405 ms per step; 1,024-thread blocks: no further gain).
 #define GMP_BN_SHORT_LAUNCH(KERNEL, MAXROWS, GRID, BLK, ST, ARGS, WIDE)                \
     do {                                                                               \
         if (WIDE) {                                                                    \
@@ -495,11 +490,6 @@ extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max
         else if ((MAXROWS) <= 16 * SRL) hipLaunchKernelGGL(KERNEL<16>, GRID, BLK, 0, ST, ARGS); \
         else hipLaunchKernelGGL((KERNEL<16, 2 * SRL>), GRID, dim3(2 * SRL * SCQ), 0, ST, ARGS);  \
     } while (0)
-
-static int bn_wide(int dflt) {
-    static const int forced = getenv("GMP_BN_WIDE") ? atoi(getenv("GMP_BN_WIDE")) : -1;
-    return forced >= 0 ? forced : dflt;
-}
 
 extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group, int S,
                           int64_t max_seg_rows, int64_t rows, int C, const float* gamma, const float* beta, float* running_mean,
@@ -520,8 +510,8 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 2) != 0);
-    } else if (max_seg_rows <= MID_MAX && bn_mid_enabled()) {
+        GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, true);
+    } else if (max_seg_rows <= MID_MAX) {
         GMP_BN_MID_LAUNCH(bn_fwd_short_kernel, max_seg_rows, S, C, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);
@@ -669,8 +659,8 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
     if (max_seg_rows <= SHORT_MAX) {
-        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, (bn_wide(3) & 1) != 0);
-    } else if (max_seg_rows <= MID_MAX && bn_mid_enabled()) {
+        GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, true);
+    } else if (max_seg_rows <= MID_MAX) {
         GMP_BN_MID_LAUNCH(bn_bwd_short_kernel, max_seg_rows, S, C, st, a);
     } else {
         const dim3 grid(S * a.chunks, C / COLS);

@@ -148,7 +148,6 @@ struct GemmArgs {
     int* sig_flag;
     int sig_value;
     int vecC;             // C (+ every group's coff) 16-byte aligned and ldc % 4 == 0: the pipelined kernel stores float4 row pieces
-    int nt_store;         // pipelined kernel: non-temporal output stores
 };
 
 thread_local int* t_sig_flag = nullptr;
@@ -427,9 +426,7 @@ int launch_pipe_tile(int tile, const GemmArgs& g, int64_t rows, int z, hipStream
 }
 
 int launch_pipe(int mode, int tile, const GemmArgs& g_in, int64_t rows, int z, hipStream_t st) {
-    GemmArgs g = g_in;
-    const char* nt = getenv("GMP_GEMM_NT_STORE");
-    g.nt_store = nt && nt[0] == '1';     // off by default: measured in the step, the consumer's L2 misses cost more (1.62 vs 1.46 ms)
+    const GemmArgs& g = g_in;
     if (mode == GMP_GEMM_NT) return launch_pipe_tile<true, true>(tile, g, rows, z, st);
     if (mode == GMP_GEMM_NN) return launch_pipe_tile<true, false>(tile, g, rows, z, st);
     return launch_pipe_tile<false, false>(tile, g, rows, z, st);
@@ -440,11 +437,9 @@ inline bool pipe_enabled() {
     const char* e = getenv("GMP_GEMM_IMPL");
     return !(e && !strcmp(e, "old"));
 }
-// smallest row count (NT / NN forms) that takes the pipelined kernel (read per call: A/B aid)
-inline int64_t pipe_min_rows() {
-    const char* e = getenv("GMP_GEMM_PIPE_MIN_ROWS");
-    return e ? atoll(e) : 1024;
-}
+// smallest row count (NT / NN forms) that takes the pipelined kernel.  (Round 3: sending the task heads' small grouped GEMMs -- 8 to 340 rows
+// per group -- through it as well changed nothing in the step, 1.413-1.415 against 1.400 ms: their chains are bound by launch boundaries.)
+inline int64_t pipe_min_rows() { return 1024; }
 inline int pipe_forced_tile() {
     const char* e = getenv("GMP_GEMM_PIPE_TILE");
     return e ? atoi(e) : -1;
@@ -525,9 +520,6 @@ extern "C" int gmp_gemm_f32(int mode, const float* A, const float* B, const floa
     if (g.splitk == 1) tile = t128 >= 4096 ? 2 : 0;     // measured on MI355X: 64x64 wins until the grid is many waves deep
     if (forced >= 0 && forced <= 2 && g.splitk == 1) tile = forced;
     // large row counts (the backbone's layer GEMMs, the link-prediction scorer): the LDS-DMA pipelined kernel
-#ifdef GMP_PIPE_DEBUG
-    if (getenv("GMP_PIPE_NOSTORE")) g.accumulate |= 0x100;
-#endif
     if (mode != GMP_GEMM_TN && M >= pipe_min_rows() && N >= 64 && pipe_ok(mode, g) && (g.splitk == 1 || N % 4 == 0)) {   // (slices are stored as float4 rows of N)
         if (g.splitk == 1) return launch_pipe(mode, pipe_pick_tile(M, N, 1), g, M, 1, st);
         // few output tiles and a long K (the caller handed over a workspace): K-slices of the pipelined kernel, summed in slice order
@@ -627,7 +619,7 @@ extern "C" int gmp_gemm_f32_grouped(int mode, const float* A, const float* B, co
         const int64_t tiles = ((N + 63) / 64) * ((g.M + 63) / 64) * groups;
         int split = 1;
         if (workspace && tiles < 384 && max_rows >= 8 * BK_DEFAULT) {
-            static const int64_t target = getenv("GMP_TN_TARGET_BLOCKS") ? atoi(getenv("GMP_TN_TARGET_BLOCKS")) : 512;   // tuning aid
+            const int64_t target = 512;
             split = (int)std::min<int64_t>((target + tiles - 1) / tiles, max_rows / (4 * BK_DEFAULT));
             const size_t need = (size_t)groups * split * (g.M * N + g.M) * sizeof(float);
             if (split < 2 || need > workspace_bytes) split = 1;

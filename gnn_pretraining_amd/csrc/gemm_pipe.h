@@ -353,19 +353,6 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
         }
     }
 
-#ifdef GMP_PIPE_DEBUG
-    if (g.accumulate & 0x100) {          // timing experiment: no epilogue stores (accumulators kept alive)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(acc[i][j]));
-#endif
-            }
-        return;
-    }
-#endif
     // ---- epilogue ------------------------------------------------------------------------------------------------------
     // The accumulators hold one COLUMN per lane (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
     // 4 * (lane >> 5)): stored as they stand that is 16 * TM * TN dword stores per lane, 256 bytes each, and with every block of
@@ -423,16 +410,9 @@ __global__ __launch_bounds__(THREADS) void gemm_pipe_kernel(const GemmArgs g, in
                 if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             if (full) {
-                // GMP_GEMM_NT_STORE=1: non-temporal stores.  With plain stores the 15 MB a layer GEMM writes stay dirty in the XCDs'
-                // L2s until the end-of-kernel write-back (+2.5 us on a 26 us launch, kernel alone); in the step the consumer then
-                // reads them from L2, and streaming them out instead made the whole step slower (1.62 vs 1.46 ms): off by default
-                if (g.nt_store) {
-                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    f32x4 w = {v.x, v.y, v.z, v.w};
-                    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(o));
-                } else {
-                    *reinterpret_cast<float4*>(o) = v;
-                }
+                // (plain stores: with non-temporal ones the kernel alone is 2.5 us shorter -- no end-of-kernel L2 write-back of the 15 MB a
+                // layer GEMM writes -- but the consumer then misses L2 and the whole step got slower, 1.62 against 1.46 ms; removed in round 3)
+                *reinterpret_cast<float4*>(o) = v;
             }
             else {
                 o[0] = v.x;

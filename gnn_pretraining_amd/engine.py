@@ -323,9 +323,9 @@ class StepEngine:
         self._neg_native = None
         # score each unordered pair once (the scorer is symmetric in (src, dst)); GMP_LP_MERGE=0 keeps the reference's ordered list
         self.lp_merge = os.environ.get("GMP_LP_MERGE", "1") != "0"
-        # row ranges of the stacked forward (gnnmp_step.h fwd_cut_*): 1 = one pass on main (GMP_FWD_SPLIT=0 is the old spelling), 2 the
-        # default, 3 measured equal or slightly worse (1.474-1.484 against 1.455-1.485 ms per step)
-        self.fwd_ranges = 1 if os.environ.get("GMP_FWD_SPLIT", "1") == "0" else max(1, min(3, int(os.environ.get("GMP_FWD_RANGES", "2"))))
+        # row ranges of the stacked forward (gnnmp_step.h fwd_cut_*): GMP_FWD_RANGES = 1 (one pass on main), 2 (default), 3 (measured equal or
+        # slightly worse: 1.474-1.484 against 1.455-1.485 ms per step)
+        self.fwd_ranges = max(1, min(3, int(os.environ.get("GMP_FWD_RANGES", "2"))))
         self.native_plan = os.environ.get("GMP_NATIVE_PLAN", "1") != "0"
         for t in tasks:
             if t not in SUPPORTED_TASKS:
@@ -479,7 +479,7 @@ class StepEngine:
         self.sync_flags = torch.zeros(64, dtype=torch.int32, device=dev)
         self._epoch = 0
         self.use_gates = bool(ST.last_report.get("calibrated") and ST.last_report.get("own_queue") == 3
-                              and os.environ.get("GMP_STEP_GATES", "1") != "0" and os.environ.get("GMP_HEAD_LAYOUT") != "per_task")
+                              and os.environ.get("GMP_STEP_GATES", "1") != "0")
         # PCGrad (and the data-parallel exchange) part by part beside the backward: needs the gates and the native executor
         # (opt-in, GMP_OPT_OVERLAP=1: measured 1.58 against 1.54 ms/step on one GPU -- 28 small launches on the exchange stream beside
         # the backward and a longer hand-over chain at the end cost more than the 58 us of Gram / solve / combine they take off it)
@@ -487,10 +487,7 @@ class StepEngine:
         self.comm_stream = extra[1]        # data-parallel exchange beside the backward (the head streams are idle by then)
         bins = [[0.0, extra[0]], [0.0, extra[1]], [0.0, self.aux_stream], [0.0, None]]      # None = the main stream
         self.task_streams = [None] * self.T
-        if os.environ.get("GMP_HEAD_LAYOUT") == "per_task":                 # A/B aid: the old one-stream-per-task layout
-            self.task_streams = [torch.cuda.Stream(device=dev) for _ in range(self.T)]
-            bins = []
-        for ti in (sorted(range(self.T), key=lambda i: -HEAD_CHAIN_US.get(self.tasks[i], 100.0)) if bins else []):
+        for ti in sorted(range(self.T), key=lambda i: -HEAD_CHAIN_US.get(self.tasks[i], 100.0)):
             b = min(bins, key=lambda x: x[0])
             b[0] += HEAD_CHAIN_US.get(self.tasks[ti], 100.0)
             self.task_streams[ti] = b[1]
@@ -1194,7 +1191,7 @@ class StepEngine:
         self.loss_sums / self.plan_sizes until someone asks (losses())."""
         import time as _t
         self._use_stream()
-        if self.rng_mode == "device" or os.environ.get("GMP_FORCE_LEAD"):
+        if self.rng_mode == "device":
             # Device draws ride the aux stream, i.e. they run behind whatever the launcher has already enqueued there: the launcher
             # therefore keeps at most two steps in front of the GPU (enough to keep it fed: enqueueing a step takes half a step), so a
             # ticket is served within two steps and the prefetcher's three tickets in flight cover it
@@ -1226,7 +1223,7 @@ class StepEngine:
         h = self.host_ms
         h["draw"] += (t1 - t0) * 1e3; h["plan"] += (t2 - t1) * 1e3; h["upload"] += (t3 - t2) * 1e3; h["launch"] += (t4 - t3) * 1e3
         h["steps"] += 1
-        if self.rng_mode == "device" or os.environ.get("GMP_FORCE_LEAD"):
+        if self.rng_mode == "device":
             e = torch.cuda.Event()
             e.record(torch.cuda.current_stream(self.device))
             self._lead[self.step_count] = e
@@ -2120,48 +2117,18 @@ class StepPrefetcher:
                     t0 = _t.perf_counter()
                     art = engine.draw(inp, gen)
                     self.draw_s += _t.perf_counter() - t0
-                    if one_stage:
-                        t0 = _t.perf_counter()
-                        item = (inp, (art, engine.plan(inp, art)))
-                        self.busy_s += _t.perf_counter() - t0
-                        self.q.put(item)
-                    else:
-                        planq.put((inp, art))
-            except BaseException as e:           # surfaced on the consumer side
-                self._err = e
-            (self.q if engine.rng_mode == "device" or one_stage else planq).put(None)
-
-        # GMP_PREFETCH_STAGES=2: a second thread lays the segments out (engine.plan: numpy, no RNG, no engine state) while this one
-        # draws the next step (native, GIL released).  Measured equal to one thread at today's step time (1.51 against 1.50 ms: the
-        # launcher never waits for either) and noisier -- three Python threads share one GIL -- so one thread is the default; the
-        # split is the headroom for a faster device half (draws 0.8 + layout 0.6 ms busy per 1.5 ms step).
-        planq: "queue.Queue" = queue.Queue(maxsize=2)
-        one_stage = os.environ.get("GMP_PREFETCH_STAGES", "1") != "2"
-
-        def layout() -> None:
-            import time as _t
-            try:
-                while True:
-                    item = planq.get()
-                    if item is None:
-                        break
-                    inp, art = item
                     t0 = _t.perf_counter()
-                    out = (inp, (art, engine.plan(inp, art)))
+                    item = (inp, (art, engine.plan(inp, art)))
                     self.busy_s += _t.perf_counter() - t0
-                    self.q.put(out)
-            except BaseException as e:
+                    self.q.put(item)
+            except BaseException as e:           # surfaced on the consumer side
                 self._err = e
             self.q.put(None)
 
-        if os.environ.get("GMP_SWITCH_INTERVAL"):
-            import sys
-            sys.setswitchinterval(float(os.environ["GMP_SWITCH_INTERVAL"]))
+        # (One thread draws and lays out.  A second, layout-only stage and shorter CPython switch intervals measured equal or worse in round 2
+        # -- three Python threads on one GIL -- and were removed in round 3.)
         self.thread = threading.Thread(target=work, daemon=True)
         self.thread.start()
-        if engine.rng_mode != "device" and not one_stage:
-            self.plan_thread = threading.Thread(target=layout, daemon=True)
-            self.plan_thread.start()
 
     def __iter__(self):
         import time as _t

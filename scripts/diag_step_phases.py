@@ -1,9 +1,7 @@
 """Phase durations of the s4 step on the GPU clock (no profiler): forward / heads / backward (+ optimizer by difference).
-GMP_STEP_TIMING=1 python scripts/diag_step_phases.py [per_task|packed]"""
+GMP_STEP_TIMING=1 python scripts/diag_step_phases.py"""
 import ctypes as C, os, sys, time
 os.environ["GMP_STEP_TIMING"] = "1"
-if len(sys.argv) > 1:
-    os.environ["GMP_HEAD_LAYOUT"] = sys.argv[1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as B
@@ -38,7 +36,7 @@ det = (C.c_float * 13)()
 L.check(L.lib().gmp_step_phase_detail_ms(det), "detail")
 print("last step detail (us): enc %.0f | fwd layers %s | heads %.0f | bwd layers 4..0 %s | tail %.0f" % (
     det[0] * 1e3, [round(det[1 + i] * 1e3) for i in range(5)], det[6] * 1e3, [round(det[7 + i] * 1e3) for i in range(5)], det[12] * 1e3))
-print(os.environ.get("GMP_HEAD_LAYOUT", "packed"), "forward %.3f heads %.3f backward %.3f ms | whole synchronous step %.3f ms" % (acc[0] / n, acc[1] / n, acc[2] / n, t_all / n))
+print("forward %.3f heads %.3f backward %.3f ms | whole synchronous step %.3f ms" % (acc[0] / n, acc[1] / n, acc[2] / n, t_all / n))
 
 # the same detail for the last step of a PIPELINED run (host several steps ahead, as in bench.py): no idle GPU in front of the step
 from gnn_pretraining_amd.pretrain.control import TemperatureScheduler
