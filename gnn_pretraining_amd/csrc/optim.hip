@@ -270,6 +270,46 @@ __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
     }
 }
 
+// Data-parallel runs that SHARD PCGrad over the ranks (dist.ShardedGradSync): a rank runs gram / solve / combine only for the tensors it owns
+// and receives every other tensor's combined gradient from its owner (all-gather into final_grad).  For those FOREIGN tensors [k0, k1) this
+// pass leaves behind exactly what the owner's solve / combine left on the owner: the "has a gradient" flag and the step count (functions
+// of the availability table and the task order alone, no Gram matrix needed), zeroed conflict / projection slots (the owner counted them),
+// and the per-chunk sums of squares of the gradient now in place -- combine_kernel's own arithmetic, so the clip norm that follows is
+// bit for bit the unsharded one.
+__global__ __launch_bounds__(TB) void foreign_kernel(MtArgs a) {
+    __shared__ float sh[TB / 64];
+    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
+    const unsigned char* has = a.has + k * MAXT;
+    int flag = a.n_order > 0 && has[a.order[0]] ? 1 : 0;                    // PCGrad emits a gradient iff the first-shuffled task has the tensor
+    if (!flag && a.last_task >= 0 && has[a.last_task]) flag = 1;            // ... else the last task's raw .grad stays (gradient_surgery.py:61)
+    if (a.extra_task >= 0 && has[a.extra_task]) flag = 1;
+    if (j == 0 && threadIdx.x == 0) {
+        a.flags[k] = flag;
+        if (a.steps && !(a.abort && *a.abort)) a.steps[k] += (float)flag;
+        a.block_metrics[2 * k] = 0;
+        a.block_metrics[2 * k + 1] = 0;
+    }
+    float ss = 0.f;
+    if (flag) {
+        const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+        const int lo = j * per, hi = min(lo + per, len4);
+        const int64_t off = a.off[k];
+        for (int i = lo + threadIdx.x; i < hi; i += TB) {
+            const float4 g = *reinterpret_cast<const float4*>(a.final_grad + off + 4 * (int64_t)i);
+            ss = fmaf(g.x, g.x, ss); ss = fmaf(g.y, g.y, ss); ss = fmaf(g.z, g.z, ss); ss = fmaf(g.w, g.w, ss);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (threadIdx.x % 64 == 0) sh[threadIdx.x / 64] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s2 = sh[0];
+        for (int w = 1; w < TB / 64; ++w) s2 += sh[w];
+        a.partial[k * CH + j] = s2;
+    }
+}
+
 __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
     __shared__ double sh[TB];
     __shared__ int shc[TB], shp[TB];
@@ -354,7 +394,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task
                                            float max_norm, float* final_grad, float* normsq_out, int32_t* metrics_out,
                                            int32_t* flags_out, void* ws, size_t ws_bytes, int apply_update,
                                            int k_begin, int k_end, int phases, const int32_t* abort_flag, gmp_stream_t stream) {
-    if (k_begin < 0 || k_end > num_tensors || k_begin > k_end || !(phases & 3))
+    if (k_begin < 0 || k_end > num_tensors || k_begin > k_end || !(phases & 7))
         return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tensors [%d, %d) of %d, phases %d", k_begin, k_end, num_tensors, phases);
     if (num_tasks < 1 || num_tasks > MAXT || num_tensors < 1 || n_order < 1 || n_order > num_tasks)
         return gmp::fail(GMP_ERR_ARG, "mt_pcgrad: tasks=%d tensors=%d n_order=%d", num_tasks, num_tensors, n_order);
@@ -392,6 +432,7 @@ extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task
         hipLaunchKernelGGL(solve_kernel, dim3((nk + 63) / 64), dim3(64), 0, st, a);
         hipLaunchKernelGGL(combine_kernel, dim3(nk, CH), dim3(TB), 0, st, a);
     }
+    if ((phases & 4) && nk > 0) hipLaunchKernelGGL(foreign_kernel, dim3(nk, CH), dim3(TB), 0, st, a);
     if (phases & 2) {
         hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
         if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);

@@ -312,8 +312,16 @@ _EMPTY_ART = {"node_feat_mask": lambda: np.zeros(0, dtype=np.int64), "link_pred"
 class StepEngine:
     def __init__(self, model: PretrainableGNN, tasks: Sequence[str], domains: Sequence[str], device,
                  max_rows: int = 16384, max_edges: int = 131072, seed: int = 0, shuffle_rng: Optional[random.Random] = None,
-                 grad_sync=None, rng_mode: str = "reference", native: bool = True, neg_rng: Optional[random.Random] = None) -> None:
+                 grad_sync=None, rng_mode: str = "reference", native: bool = True, neg_rng: Optional[random.Random] = None,
+                 dp_mode: Optional[str] = None) -> None:
         self.native = native       # True: csrc/step.hip enqueues the step; False: the same launches one by one from Python
+        # data-parallel exchange: "allreduce" (every rank all-reduces all per-task gradients and runs the whole PCGrad: dist.OverlappedGradSync)
+        # or "sharded" (reduce-scatter to the owner of each tensor, PCGrad on the owned tensors, all-gather of the combined gradient:
+        # dist.ShardedGradSync -- 30 % fewer bytes, PCGrad 1/W per rank; needs the native executor)
+        self.dp_mode = dp_mode or os.environ.get("GMP_DP_MODE", "allreduce")
+        if self.dp_mode not in ("allreduce", "sharded"):
+            raise ValueError("dp_mode must be 'allreduce' or 'sharded'")
+        self._shard_sync_obj = None
         if rng_mode not in ("reference", "vectorized", "device"):
             raise ValueError("rng_mode must be 'reference', 'vectorized' or 'device'")
         self.rng_mode, self._nprng = rng_mode, None
@@ -1702,6 +1710,15 @@ class StepEngine:
                 (self.sync_flags.data_ptr() + 4 * 63) if self.use_gates else None,      # a timed-out gate: no update from this step on
                 stream), "mt_pcgrad_clip_adamw")
 
+        if self.grad_sync is not None and self.dp_mode == "sharded" and self.native:
+            from . import dist as D
+            if D.world_size() > 1:
+                sync = self._shard_sync()
+                sync.average_(self.lib, torch.cuda.current_stream(self.device),
+                              gate=(self.sync_flags.data_ptr(), self._epoch) if self.use_gates else None,
+                              own_pass=lambda a, b, st: pcgrad(a, b, 1, st), foreign_pass=lambda a, b, st: pcgrad(a, b, 4, st))
+                pcgrad(0, self.K, 2, self._st())
+                return
         if self.parts_beside_backward:
             # PCGrad follows the backward part by part on the exchange stream (Gram / solve / combine of a part as soon as its
             # gradients are final -- and, data parallel, averaged); only the total norm, the clip and AdamW wait for the last part
@@ -1755,6 +1772,22 @@ class StepEngine:
                                              for b in range(1, GNN_NUM_LAYERS + 2)]
             self._packed_sync = OverlappedGradSync(self.task_grads.view(-1), parts, self.comm_stream)
         return self._packed_sync
+
+    def _shard_sync(self):
+        """dist.ShardedGradSync over the same parts as _part_sync: tensor k's message slices = one copy per task that has it (static table),
+        its combined gradient = its slot of final_grad."""
+        if self._shard_sync_obj is None:
+            from .dist import ShardedGradSync
+            self._part_sync()                                  # builds self._part_tensors (and checks the parts are runs of tensor indices)
+            al4 = lambda v: -(-v // 4) * 4
+
+            def msg(k: int):
+                n = self.names[k]
+                return [(t * self.P + self.off[n], al4(self.numel[n])) for t in range(self.T) if self.has_static[k][t]]
+
+            fin = lambda k: (self.off[self.names[k]], al4(self.numel[self.names[k]]))
+            self._shard_sync_obj = ShardedGradSync(self.task_grads.view(-1), self.final_grad, self._part_tensors, msg, fin, self.comm_stream)
+        return self._shard_sync_obj
 
     @staticmethod
     def _part_of(name: str) -> int:

@@ -467,7 +467,10 @@ int gmp_mt_pcgrad_clip_adamw(const float* task_grads, int64_t task_stride, int n
 /* The same in pieces, so PCGrad can follow the backward part by part: phases bit 0 = Gram / solve / combine for the tensors
  * [k_begin, k_end) only (their final_grad, flags, step counts, norm partials), bit 1 = total norm + clip + AdamW over ALL tensors
  * (call it once, after bit 0 has covered every tensor; same stream order or an explicit dependency in between).  Results are
- * bitwise those of the one-shot call: every tensor's arithmetic is independent of the others up to the norm. */
+ * bitwise those of the one-shot call: every tensor's arithmetic is independent of the others up to the norm.
+ * bit 2 (value 4), for data-parallel runs that shard PCGrad over the ranks: the tensors [k_begin, k_end) are FOREIGN -- their combined
+ * gradient was computed by another rank and already stands in final_grad (all-gathered); this leaves their flag, step count and norm
+ * partials as the owner's bit 0 pass left them there, without touching task_grads (gnn_pretraining_amd/dist.py ShardedGradSync). */
 int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task_stride, int num_tasks, int num_tensors,
                                 const int64_t* tensor_off, const int32_t* tensor_len, const uint8_t* has,
                                 const int32_t* order_host, int n_order, int last_task, int extra_task,

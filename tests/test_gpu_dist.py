@@ -38,8 +38,8 @@ def _inputs(rank, eng):
     return StepInputs(S.pretrain_step_batches(gen, PT.PRETRAIN_DOMAINS["s4"]), eng.device, eng.dpad), gen
 
 
-def _worker(rank, world, port, out, overlap):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GMP_DP_OVERLAP=overlap)
+def _worker(rank, world, port, out, overlap, mode="allreduce"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GMP_DP_OVERLAP=overlap, GMP_DP_MODE=mode)
     import torch.distributed as dist
     from gnn_pretraining_amd import dist as D
     D.init_from_env("gloo")
@@ -47,12 +47,13 @@ def _worker(rank, world, port, out, overlap):
     inp, gen = _inputs(rank, eng)
     eng.step(inp, gen)
     torch.cuda.synchronize()
-    first = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu()}
+    first = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu(), "final": eng.final_grad.cpu(), "normsq": eng.normsq.cpu(), "flags": eng.flags.cpu()}
     eng.step(inp, gen)                                                      # a second step: the events / message buffers are reused
     torch.cuda.synchronize()
-    sync = eng._packed_sync
-    parts = [list(zip(p.table[:p.n].tolist(), (p.table[p.n + 1:] - p.table[p.n:-1]).tolist())) for p in getattr(sync, "parts", [sync])]
-    out[rank] = dict(first, flat2=eng.flat.cpu(), parts=parts, kind=type(sync).__name__)
+    sync = eng._shard_sync_obj if mode == "sharded" else eng._packed_sync
+    parts = [list(zip(p.table[:p.n].tolist(), (p.table[p.n + 1:] - p.table[p.n:-1]).tolist())) for p in getattr(sync, "parts", [sync])] if mode != "sharded" else []
+    extra = {"own": [m["own_k"] for m in sync.msgs], "rs_floats": sync.total_rs, "ag_floats": sync.total_ag} if mode == "sharded" else {}
+    out[rank] = dict(first, flat2=eng.flat.cpu(), m2=eng.exp_avg.cpu(), v2=eng.exp_avg_sq.cpu(), steps=eng.steps.cpu(), parts=parts, kind=type(sync).__name__, **extra)
     dist.destroy_process_group()
 
 
@@ -116,3 +117,28 @@ def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical(overlap):
     assert checked > 100
     assert torch.equal(out[0]["flat"], out[1]["flat"])                      # identical update on both ranks
     assert torch.equal(out[0]["tg"], out[1]["tg"])
+
+
+def test_sharded_exchange_equals_the_allreduce_exchange_bitwise():
+    """dist.ShardedGradSync: every tensor has one owner rank; reduce-scatter of the per-task gradients, PCGrad on the owned
+    tensors only, all-gather of the combined gradient, the foreign pass, then norm / clip / AdamW everywhere.  Two ranks on different shards,
+    two steps: combined gradient, clip norm, flags, step counts, parameters and both Adam moments BITWISE equal to the all-reduce exchange's
+    (with two ranks a sum of two addends is the same in either collective), replicas identical, every tensor owned exactly once, fewer floats sent."""
+    world = 2
+    res = {}
+    for mode in ("allreduce", "sharded"):
+        out = mp.Manager().dict()
+        mp.spawn(_worker, args=(world, _free_port(), out, "1", mode), nprocs=world, join=True)
+        res[mode] = {r: out[r] for r in range(world)}
+    a, s = res["allreduce"], res["sharded"]
+    assert s[0]["kind"] == "ShardedGradSync" and a[0]["kind"] == "OverlappedGradSync"
+    for r in range(world):
+        for key in ("final", "normsq", "flags", "flat", "flat2", "m2", "v2", "steps"):
+            assert torch.equal(s[r][key], a[r][key]), (r, key)
+    assert torch.equal(s[0]["flat2"], s[1]["flat2"])
+    # ownership: the ranks' runs of tensor indices are disjoint and together cover every tensor once
+    owned = sorted(k for r in range(world) for msg in s[r]["own"] for (k0, k1) in msg for k in range(k0, k1))
+    assert owned == list(range(len(owned))) and len(owned) == int(a[0]["flags"].numel())
+    # bytes: a ring all-reduce moves 2 (W-1)/W x message, reduce-scatter + all-gather (W-1)/W x (message + combined gradient)
+    allreduce_floats = 2 * sum(n for part in a[0]["parts"] for (_, n) in part)
+    assert s[0]["rs_floats"] // world + s[0]["ag_floats"] // world < 0.8 * allreduce_floats
