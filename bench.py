@@ -466,7 +466,8 @@ def main() -> None:
                                    if engine.lp_merge else "the reference's ordered list (GMP_LP_MERGE=0)"), "gates_verified_under_communicator": gates_checked,
                        "ranks": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
                        "devices_visible": torch.cuda.device_count(),
-                       "gradient_exchange": (type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
+                       "gradient_exchange": (type(engine._shard_sync_obj).__name__ if engine._shard_sync_obj is not None else
+                                             type(engine._packed_sync).__name__ if engine._packed_sync is not None else None)},
             "roofline": roof, "cpu_baseline": cpu, "roofline_gemm": roof_gemm, "roofline_bwd": ROOFLINE_BWD, "cora_finetune": cora,
         }
         emit(line)

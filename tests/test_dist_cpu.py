@@ -89,3 +89,20 @@ def test_overlapped_exchange_groups_parts_into_messages(monkeypatch):
         monkeypatch.setenv("GMP_DP_GROUPS", bad)
         with pytest.raises(ValueError):
             OverlappedGradSync(base, parts, comm=None)
+
+
+def test_owner_shares_are_contiguous_cover_everything_and_balance():
+    """dist.split_by_weight (the tensor -> owner-rank map of the sharded exchange): contiguous shares, every item once, empty shares allowed,
+    and no share heavier than the fair share plus one item."""
+    import random
+    from gnn_pretraining_amd.dist import split_by_weight
+    rng = random.Random(3)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 62):
+            w = [rng.choice([4, 256, 512, 65536, 131072]) for _ in range(n)]
+            c = split_by_weight(w, world)
+            assert len(c) == world + 1 and c[0] == 0 and c[-1] == n and all(a <= b for a, b in zip(c[:-1], c[1:]))
+            if n:
+                fair, big = sum(w) / world, max(w)
+                assert all(sum(w[a:b]) <= fair + big for a, b in zip(c[:-1], c[1:]))
+    assert split_by_weight([10, 10, 10], 3) == [0, 1, 2, 3]
