@@ -26,6 +26,21 @@ __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
 }
 __device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// A row piece out of LDS through an address-space-3 pointer.  `cond ? s_x[i] : x[j]` with both sides reached through generic pointers is
+// compiled to ONE flat_load of a selected address -- and a flat load is waited for with s_waitcnt vmcnt(0) lgkmcnt(0), which also waits for
+// every global prefetch in flight behind it: in the tile kernel below that serialised "prefetch the next tile" and "reduce this one"
+// (round 3: found in the ISA).  A load through a typed LDS pointer cannot be merged with a global one: ds_read_b128, lgkmcnt only.
+typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) lds_f32x4* lds_row_ptr;
+typedef const __attribute__((address_space(3))) int* lds_int_ptr;
+// Pins a value where it is: an LDS-only branch ends with this so that the optimiser cannot sink its additions into a block shared with
+// the branch that reads global memory -- the shared block would wait for BOTH counters (vmcnt(0) lgkmcnt(0)) on every path.
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ float4 lds_f4(lds_row_ptr p, int i) {
+    const lds_f32x4 v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // NV = float4 per lane (F <= 256*NV).  SELF: out = scale*self + sum.  DOT: also write
 // rowdot[r] = <self[r], dotx[r]> (eps gradient, reduced per task afterwards).  ADDEND: out += addend[r]
 // (the residual branch's gradient joins the aggregation's in the same pass).
@@ -217,27 +232,44 @@ __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4*
         }
         if (t + 1 < tend) GMP_PREFETCH_TILE(t + 1, eB, eC);   // in flight while this tile is reduced out of LDS
         const int r0i = (int)r0;
-        auto row_of = [&](int u) -> float4 {
+        const lds_row_ptr sx3 = (lds_row_ptr)smem;
+        auto row_of = [&](int u) -> float4 {              // u is wave-uniform: a scalar branch, two differently typed loads (never one flat load)
             const unsigned loc = (unsigned)(u - r0i);
-            return loc < (unsigned)nr ? s_x[loc * 64 + lane] : x[(int64_t)u * 64 + lane];
+            if (loc < (unsigned)nr) return lds_f4(sx3, loc * 64 + lane);
+            return x[(int64_t)u * 64 + lane];
         };
         static_assert(!DOT || SB / GMP_WAVE * XPT >= TILE, "DOT: every row of the tile has a register slot");
+        const lds_int_ptr sc3 = (lds_int_ptr)s_col, sp3 = (lds_int_ptr)s_ptr;
         auto reduce_row = [&](int rr) {
-            const int start = s_ptr[rr], end = s_ptr[rr + 1];
-            float4 acc = s_x[rr * 64 + lane];
+            const int start = sp3[rr], end = sp3[rr + 1];
+            float4 acc = lds_f4(sx3, rr * 64 + lane);
             acc = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
             int e = start;
             for (; e + 4 <= end; e += 4) {
                 int c0, c1, c2, c3;
-                if (staged) { c0 = s_col[e - base]; c1 = s_col[e - base + 1]; c2 = s_col[e - base + 2]; c3 = s_col[e - base + 3]; }
+                if (staged) { c0 = sc3[e - base]; c1 = sc3[e - base + 1]; c2 = sc3[e - base + 2]; c3 = sc3[e - base + 3]; }
                 else { c0 = col[e]; c1 = col[e + 1]; c2 = col[e + 2]; c3 = col[e + 3]; }
-                const float4 a = row_of(__builtin_amdgcn_readfirstlane(c0)), b = row_of(__builtin_amdgcn_readfirstlane(c1));
-                const float4 c = row_of(__builtin_amdgcn_readfirstlane(c2)), d = row_of(__builtin_amdgcn_readfirstlane(c3));
-                acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
+                const int u0 = __builtin_amdgcn_readfirstlane(c0), u1 = __builtin_amdgcn_readfirstlane(c1);
+                const int u2 = __builtin_amdgcn_readfirstlane(c2), u3 = __builtin_amdgcn_readfirstlane(c3);
+                const unsigned l0 = (unsigned)(u0 - r0i), l1 = (unsigned)(u1 - r0i), l2 = (unsigned)(u2 - r0i), l3 = (unsigned)(u3 - r0i);
+                if (staged && l0 < (unsigned)nr && l1 < (unsigned)nr && l2 < (unsigned)nr && l3 < (unsigned)nr) {
+                    // the common case (whole graphs inside the tile): LDS only -- no vector-memory wait on this path, the next tile's
+                    // prefetch stays in flight behind it
+                    const float4 a = lds_f4(sx3, l0 * 64 + lane), b = lds_f4(sx3, l1 * 64 + lane);
+                    const float4 c = lds_f4(sx3, l2 * 64 + lane), d = lds_f4(sx3, l3 * 64 + lane);
+                    acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
+                    pin4(acc);
+                } else {
+                    const float4 a = row_of(u0), b = row_of(u1), c = row_of(u2), d = row_of(u3);
+                    acc = f4add(f4add(f4add(f4add(acc, a), b), c), d);
+                }
             }
             for (; e < end; ++e) {
-                const int cc = staged ? s_col[e - base] : col[e];
-                acc = f4add(acc, row_of(__builtin_amdgcn_readfirstlane(cc)));
+                const int cc = staged ? sc3[e - base] : col[e];
+                const int u = __builtin_amdgcn_readfirstlane(cc);
+                const unsigned l = (unsigned)(u - r0i);
+                if (l < (unsigned)nr) { acc = f4add(acc, lds_f4(sx3, l * 64 + lane)); pin4(acc); }
+                else acc = f4add(acc, x[(int64_t)u * 64 + lane]);
             }
             if (NT_STORE) {
                 float* o = reinterpret_cast<float*>(out + (r0 + rr) * 64 + lane);
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(SB) void gin_aggregate_ldstile_kernel(const float4*
                 const int rr = wv + kq * SWAVES;
                 if (rr >= nr) break;
                 if (kq + AHEAD < XPT) qx[kq + AHEAD] = load_q(kq + AHEAD);
-                const float4 g = s_x[rr * 64 + lane];
+                const float4 g = lds_f4(sx3, rr * 64 + lane);
                 const float d = gmp::wave_sum((g.x * qx[kq].x + g.y * qx[kq].y) + (g.z * qx[kq].z + g.w * qx[kq].w));
                 if (lane == 0) rowdot[r0 + rr] = d;
                 reduce_row(rr);
@@ -385,7 +417,7 @@ extern "C" int gmp_gin_aggregate_fwd(const float* x, const int32_t* rowptr, cons
     if (N < 0 || (N > 0 && (!x || !rowptr || !out))) return gmp::fail(GMP_ERR_ARG, "gin_aggregate_fwd: null pointer");
     if (N == 0) return GMP_OK;
     const int F4 = feat / 4;
-    if (feat == 256 && N >= 65536)            // working set beyond the caches: LDS-resident 144-row tiles (153 KB of the CU's 160 KB), 1,024 threads, one block per CU
+    if (feat == 256 && N >= 65536)            // working set beyond the caches: LDS-resident tiles, 1,024 threads, one block per CU
         return launch_ldstile144<false>(x, rowptr, col, eps, out, N, nullptr, nullptr, (hipStream_t)stream);
     Plan p = make_plan(N);
     return launch_nv<true, true, false, false, false>((F4 + 63) / 64, p, (hipStream_t)stream, x, rowptr, col, x, eps,
