@@ -75,9 +75,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # lines of csrc/aggregate.hip between its [pmc-stamp-begin] / [pmc-stamp-end] markers (the kernel the passes measured, and its
 # launcher) still hash to PMC_SOURCE_SHA16 and the rung is PMC_SHAPE; null otherwise (re-measure: profiles/README.md).
 PMC_SHAPE = (2146816, 8068480)
-PMC_TRAFFIC_BYTES = int((1229083.6 * 2 + 2146899.6) * 1024)     # profiles/r02b_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
-PMC_TRAFFIC_BYTES_BWD = int((2689371.2 * 2 + 2167702.9) * 1024) # same file, backward with the eps row products (1.16 x algorithmic)
-PMC_SOURCE_SHA16 = "71aa7c7be9734a64"                           # sha256 of the marked region of the measured source, first 16 hex digits
+PMC_TRAFFIC_BYTES = int((1230567.3 * 2 + 2146853.9) * 1024)     # profiles/r03_pmc_aggregate_fwd_bwd.csv (forward: 1.063 x algorithmic)
+PMC_TRAFFIC_BYTES_BWD = int((2744854.8 * 2 + 2169640.2) * 1024) # same file, backward with the eps row products (1.18 x algorithmic)
+PMC_SOURCE_SHA16 = "e27842a84e2faf0b"                           # sha256 of the marked region of the measured source, first 16 hex digits
 
 
 def pmc_source_sha16():
