@@ -314,7 +314,18 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
     __shared__ double sh[TB];
     __shared__ int shc[TB], shp[TB];
     double s = 0.0;
-    for (int i = threadIdx.x; i < a.K * CH; i += TB) s += (double)a.partial[i];
+    {   // float4 loads, all of a thread's in flight together: one dependent load after the other cost 8 of this launch's 12.6 us (r03a trace)
+        const float4* p4 = reinterpret_cast<const float4*>(a.partial);
+        const int n4 = a.K * CH / 4;                    // CH is a multiple of 4 and the buffer 16-byte aligned
+        constexpr int U = 8;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += U * TB) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = i0 + u * TB < n4 ? p4[i0 + u * TB] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+        }
+    }
     // the conflict / projection counts ride the same tree (one thread walking the K slots one dependent load after the other was
     // 8 of this launch's 12 us, on the serial tail of the step)
     int c = 0, pr = 0;
