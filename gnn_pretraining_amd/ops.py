@@ -40,6 +40,16 @@ def _need(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> None:
         raise L.GnnmpError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
 
 
+def _need_rows(t: Tensor, name: str) -> None:
+    """2-D fp32 GPU tensor whose rows are contiguous (stride 1 along a row, leading dimension >= the row length)."""
+    if not t.is_cuda:
+        raise L.GnnmpError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback), got {t.device}")
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise L.GnnmpError(f"{name}: expected a 2-D {torch.float32} tensor, got {t.dtype} {tuple(t.shape)}")
+    if t.numel() and (t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1))):
+        raise L.GnnmpError(f"{name}: rows must be contiguous (strides {t.stride()})")
+
+
 def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -166,8 +176,10 @@ NT, NN, TN = 0, 1, 2
 
 def gemm(mode: int, A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None,
          alpha: float = 1.0, accumulate: bool = False, relu: bool = False) -> Tensor:
-    """NT: A[M,K] B[N,K]^T ; NN: A[M,K] B[K,N] ; TN: A[K,M]^T B[K,N]."""
-    _need(A, torch.float32, "A", 2); _need(B, torch.float32, "B", 2)
+    """NT: A[M,K] B[N,K]^T ; NN: A[M,K] B[K,N] ; TN: A[K,M]^T B[K,N].  Operands may be row-strided views (unit stride along a row, any
+    leading dimension >= the row length): the fine-tune engine keeps the encoder weight as a [256, 1433] view of its K-padded [256, 1440]
+    slot, and evaluation through the module multiplies by that view."""
+    _need_rows(A, "A"); _need_rows(B, "B")
     if mode == NT:
         M, K, N = A.size(0), A.size(1), B.size(0); kb = B.size(1)
     elif mode == NN:
@@ -192,7 +204,8 @@ def gemm(mode: int, A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Op
     l = L.lib()
     wsb = l.gmp_gemm_f32_workspace_bytes(mode, M, N, K)
     ws = _ws(wsb, A.device) if wsb else None
-    L.check(l.gmp_gemm_f32(mode, _ptr(A), _ptr(B), _ptr(bias), _ptr(out), M, N, K, A.size(1), B.size(1), N,
+    L.check(l.gmp_gemm_f32(mode, _ptr(A), _ptr(B), _ptr(bias), _ptr(out), M, N, K, A.stride(0) if A.size(0) > 1 else A.size(1),
+                           B.stride(0) if B.size(0) > 1 else B.size(1), N,
                            float(alpha), int(accumulate), int(relu), _ptr(ws), wsb, _stream(A)), "gmp_gemm_f32")
     return out
 

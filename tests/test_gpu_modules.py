@@ -345,6 +345,16 @@ def test_finetune_node_classification_engine_matches_the_oracle_step():
     # a second step runs from the updated state (moments, step counters) and keeps the loss finite
     eng.step(idx.to(DEV), c.y[idx].to(DEV))
     assert np.isfinite(eng.loss())
+    # evaluation goes through the MODULE (finetune.evaluate): its encoder weight is now a row-strided [256, 1433] view of the engine's
+    # K-padded slot -- the module forward must take it (round 3: the CLI crashed at its first validation pass) and agree with the engine's
+    hm.eval()
+    with torch.no_grad():
+        logits_mod = hm(Batch.from_data_list([c]).to(DEV))
+    assert not hm.input_encoder.linear.weight.is_contiguous()
+    logits_eng = eng.forward()
+    torch.cuda.synchronize()
+    assert_close(logits_mod, logits_eng.cpu(), 1e-4, "module forward on the engine's strided encoder weight")
+    hm.train()
 
 
 def test_finetune_engine_graph_replay_equals_the_eager_steps():
