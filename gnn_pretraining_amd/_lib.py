@@ -63,7 +63,8 @@ class AugViewsJob(C.Structure):          # gmp_aug_views_job
 
 class BnConfig(C.Structure):
     _fields_ = [("training", C.c_int), ("relu", C.c_int), ("eps", C.c_float), ("momentum", C.c_float),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("seed_dev", C.c_void_p)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("seed_dev", C.c_void_p),
+                ("sync", C.c_void_p), ("sync_words", C.c_uint32)]
 
 
 _SIGS: Dict[str, tuple] = {
@@ -88,6 +89,7 @@ _SIGS: Dict[str, tuple] = {
     "gmp_colsum_workspace_bytes": (sz, [i64, i64]),
     "gmp_colsum": (C.c_int, [p, p, i64, i64, i64, i32, p, sz, p]),
     "gmp_bn_workspace_bytes": (sz, [i64, i32, i32, i64]),
+    "gmp_bn_sync_bytes": (sz, [i32, i32]),
     "gmp_bn_fwd": (C.c_int, [p, p, p, p, i32, i64, i64, i32, p, p, p, p, p, p, p, C.POINTER(BnConfig), p, sz, p]),
     "gmp_bn_param_grads": (C.c_int, [p, i32, i32, p, p, p, p, p, i32, p]),
     "gmp_bn_running_update_batch": (C.c_int, [i32, p, i32, p, p, p, p, p, p, p, p]),

@@ -50,6 +50,10 @@ struct BnArgs {
     float* part;    // long regime: chunk partials
     float* segsum;  // bwd: [S][2][C] (sum g, sum g*xhat)
     int chunks;     // chunks per segment (long regime)
+    int slabs;      // row slabs per segment (slab regime)
+    float* pg_gamma;   // slab regime, one segment = one gradient group: the parameter gradients, written by the kernel itself (nullable)
+    float* pg_beta;
+    int fold_running;  // slab regime, one segment: the forward kernel also folds the batch statistics into running_mean / running_var
     gmp_bn_config cfg;
 };
 
@@ -431,6 +435,255 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_long_kernel(BnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ slab regime
+// Segments of SHORT_MAX < rows <= SLAB_MAX when the caller passes rendezvous words (gmp_bn_config.sync): the 2,708-node Cora graph is
+// ONE segment, and a (segment, column strip) tile owned by one workgroup is bound by ONE CU's bandwidth (18.5 us forward, 34 us
+// backward for 5.5 MB, r03 trace; the three chunked launches were no faster).  Here the segment's rows are cut into slabs of
+// SLAB_ROWS; workgroup (slab, strip) keeps its 128 x 32 tile in registers, publishes its partial statistics, MEETS the other slabs
+// of its (segment, strip) through a counter, combines all partials in a fixed order (so every workgroup derives bit-identical
+// statistics, whatever the arrival order) and applies -- one read and one write per element on the whole chip, one launch.
+// Progress: the slabs of a group are consecutive in dispatch order (slab = fastest grid index), so a group's workgroups become
+// resident together as soon as earlier groups retire; a meeting that lasts SLAB_TIMEOUT (words not zeroed by the caller) gives up
+// and raises sync[0].  The last workgroup to leave a group resets its two words: calls leave the buffer as they found it.
+constexpr int SLAB_RPT = 4, SLAB_ROWS = SLAB_RPT * SRL, SLAB_MAX = SRL * SLAB_ROWS;    // 128-row slabs, at most 32 of them (one per row lane)
+constexpr unsigned long long SLAB_TIMEOUT_TICKS = 200000000ull;                         // 2 s of the 100 MHz wall clock
+
+__device__ __forceinline__ int* slab_words(const BnArgs& a, int s) { return a.cfg.sync + 2 + 2 * (s * (int)gridDim.y + (int)blockIdx.y); }
+
+// Partials cross workgroups (and XCDs, each with its own L2) inside one launch: written and read with agent-scope (`sc1`) accesses, NOT behind
+// agent-scope fences -- with `__threadfence()` on both sides of the meeting (352 workgroups writing back and invalidating caches twice each)
+// the launch was 25 us SLOWER than the form it replaces.
+// Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility): every byte stored `sc1` by 16-byte stores that fill whole 128-byte lines
+// (the eight column quads of row lane 0 = eight lanes of wave 0), the storing wave drains its stores, a workgroup barrier, ONE lane adds to the
+// group's counter; the reader polls the counter with `sc1` loads, a workgroup barrier, then `sc1` 16-byte loads.  (Scalar `sc1` stores are
+// one fabric write each: as `__hip_atomic_store` per float the launch took 17 us.)
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4x2_agent(float* p, float4 v, float* q, float4 w) {      // two 16-byte write-through stores, drained
+    const f4v a = {v.x, v.y, v.z, v.w}, b = {w.x, w.y, w.z, w.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(a), "v"(q), "v"(b) : "memory");
+}
+__device__ __forceinline__ void ld4x2_agent(const float* p, const float* q, float4* v, float4* w) {   // two 16-byte L1-bypassing loads, waited
+    f4v a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p), "v"(q) : "memory");
+    *v = make_float4(a.x, a.y, a.z, a.w);
+    *w = make_float4(b.x, b.y, b.z, b.w);
+}
+
+__device__ __forceinline__ void slab_meet(const BnArgs& a, int s, int nslab) {
+    __syncthreads();                   // (s_waitcnt vmcnt(0) + barrier) every partial store of this workgroup has been acknowledged
+    if (threadIdx.x == 0) {
+        int* w = slab_words(a, s);
+        __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned i = 1;; ++i) {   // exit every workgroup reaches: all slabs arrived, or the wall clock says they are not coming
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nslab) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((i & 1023u) == 0 && wall_clock64() - t0 > SLAB_TIMEOUT_TICKS) {
+                atomicOr(a.cfg.sync, 1);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void slab_leave(const BnArgs& a, int s, int nslab) {
+    if (threadIdx.x == 0) {
+        int* w = slab_words(a, s);
+        if (__hip_atomic_fetch_add(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslab - 1) {   // everybody is past the meeting
+            __hip_atomic_store(w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// (count, mean, centred sum of squares) of a set of rows; merge = Chan et al.  An empty side leaves the other unchanged, bit for bit.
+struct Mom {
+    float n;
+    float4 mean, m2;
+};
+__device__ __forceinline__ Mom mom_merge(const Mom& p, const Mom& q) {
+    const float nt = p.n + q.n;
+    if (nt == 0.f) return p;
+    const float fq = q.n / nt, w = p.n * fq;
+    const float4 d = sub4(q.mean, p.mean);
+    Mom r;
+    r.n = nt;
+    r.mean = make_float4(fmaf(d.x, fq, p.mean.x), fmaf(d.y, fq, p.mean.y), fmaf(d.z, fq, p.mean.z), fmaf(d.w, fq, p.mean.w));
+    r.m2 = make_float4(p.m2.x + q.m2.x + d.x * d.x * w, p.m2.y + q.m2.y + d.y * d.y * w, p.m2.z + q.m2.z + d.z * d.z * w, p.m2.w + q.m2.w + d.w * d.w * w);
+    return r;
+}
+__device__ __forceinline__ float4 shfl4(float4 v, int o) {
+    return make_float4(__shfl_xor(v.x, o, 64), __shfl_xor(v.y, o, 64), __shfl_xor(v.z, o, 64), __shfl_xor(v.w, o, 64));
+}
+
+template <int RPT>
+__global__ __launch_bounds__(THREADS) void bn_fwd_slab_kernel(BnArgs a) {
+    __shared__ float4 sh[SRL / 8][SCQ];
+    __shared__ float4 shm[SRL / 8][2][SCQ];
+    __shared__ float shn[SRL / 8];
+    const int s = blockIdx.x / a.slabs, j = blockIdx.x % a.slabs;
+    const int cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ, c = blockIdx.y * SCOLS + cq * 4;
+    const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1], n = seg1 - seg0;
+    constexpr int ROWS = RPT * SRL;
+    const int nslab = (n + ROWS - 1) / ROWS;
+    if (j >= nslab) return;                                  // block-uniform: slabs past the segment's end take no part
+    const int r0 = seg0 + j * ROWS, r1 = min(r0 + ROWS, seg1);
+    float4 u[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        u[i] = r < r1 ? load_u(a, (int64_t)r * a.C + c) : zero4();
+    }
+    float4 mean, rstd;
+    if (a.cfg.training) {
+        float4 acc = zero4();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) acc = add4(acc, u[i]);
+        const float4 lmean = scl4(colsum_t<SRL, SCQ>(acc, sh, rl, cq), 1.f / (r1 - r0));
+        acc = zero4();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            if (r0 + rl + i * SRL < r1) {
+                const float4 d = sub4(u[i], lmean);
+                acc = add4(acc, mul4(d, d));
+            }
+        const float4 lm2 = colsum_t<SRL, SCQ>(acc, sh, rl, cq);
+        if (rl == 0) {
+            float* p = a.part + ((int64_t)(s * a.slabs + j) * 2) * a.C + c;
+            st4x2_agent(p, lmean, p + a.C, lm2);
+        }
+        slab_meet(a, s, nslab);
+        Mom m;                                               // row lane rl holds slab rl's partial
+        m.n = rl < nslab ? (float)min(ROWS, n - rl * ROWS) : 0.f;
+        m.mean = zero4();
+        m.m2 = zero4();
+        if (rl < nslab) {
+            const float* p = a.part + ((int64_t)(s * a.slabs + rl) * 2) * a.C + c;
+            ld4x2_agent(p, p + a.C, &m.mean, &m.m2);
+        }
+        slab_leave(a, s, nslab);
+#pragma unroll
+        for (int o = SCQ; o < 64; o <<= 1) {                 // the eight row lanes of a wave; (lower lane, higher lane) whoever computes
+            Mom q;
+            q.n = __shfl_xor(m.n, o, 64);
+            q.mean = shfl4(m.mean, o);
+            q.m2 = shfl4(m.m2, o);
+            m = (threadIdx.x & o) ? mom_merge(q, m) : mom_merge(m, q);
+        }
+        if ((rl & 7) == 0) {
+            shm[rl >> 3][0][cq] = m.mean;
+            shm[rl >> 3][1][cq] = m.m2;
+            if (cq == 0) shn[rl >> 3] = m.n;
+        }
+        __syncthreads();
+        m.n = shn[0];
+        m.mean = shm[0][0][cq];
+        m.m2 = shm[0][1][cq];
+#pragma unroll
+        for (int w = 1; w < SRL / 8; ++w) {                  // waves in order: slabs 0-7, 8-15, ...
+            Mom q;
+            q.n = shn[w];
+            q.mean = shm[w][0][cq];
+            q.m2 = shm[w][1][cq];
+            m = mom_merge(m, q);
+        }
+        mean = m.mean;
+        const float inv_n = 1.f / n;
+        rstd = make_float4(rsqrtf(m.m2.x * inv_n + a.cfg.eps), rsqrtf(m.m2.y * inv_n + a.cfg.eps), rsqrtf(m.m2.z * inv_n + a.cfg.eps),
+                           rsqrtf(m.m2.w * inv_n + a.cfg.eps));
+        if (j == 0 && rl == 0) {
+            st4(a.save_mean + (int64_t)s * a.C + c, mean);
+            st4(a.save_rstd + (int64_t)s * a.C + c, rstd);
+            if (a.fold_running) {                            // one segment, one parameter set: bn_running_kernel's arithmetic
+                const float mo = a.cfg.momentum, k = n > 1 ? (float)n / (float)(n - 1) : 1.f;
+                const float4 rm = ld4(a.running_mean + c), rv = ld4(a.running_var + c);
+                const float4 var = make_float4(1.f / (rstd.x * rstd.x) - a.cfg.eps, 1.f / (rstd.y * rstd.y) - a.cfg.eps,
+                                               1.f / (rstd.z * rstd.z) - a.cfg.eps, 1.f / (rstd.w * rstd.w) - a.cfg.eps);
+                st4(a.running_mean + c, make_float4((1.f - mo) * rm.x + mo * mean.x, (1.f - mo) * rm.y + mo * mean.y,
+                                                    (1.f - mo) * rm.z + mo * mean.z, (1.f - mo) * rm.w + mo * mean.w));
+                st4(a.running_var + c, make_float4((1.f - mo) * rv.x + mo * (var.x * k), (1.f - mo) * rv.y + mo * (var.y * k),
+                                                   (1.f - mo) * rv.z + mo * (var.z * k), (1.f - mo) * rv.w + mo * (var.w * k)));
+            }
+        }
+    } else {
+        stats_for(a, s, c, &mean, &rstd);
+    }
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        if (r < r1) {
+            const int64_t off = (int64_t)r * a.C + c;
+            float4 gate;
+            st4(a.y + off, bn_apply(a, u[i], mean, rstd, gam, bet, off >> 2, &gate));
+        }
+    }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(THREADS) void bn_bwd_slab_kernel(BnArgs a) {
+    __shared__ float4 sh[SRL / 8][SCQ];
+    const int s = blockIdx.x / a.slabs, j = blockIdx.x % a.slabs;
+    const int cq = threadIdx.x % SCQ, rl = threadIdx.x / SCQ, c = blockIdx.y * SCOLS + cq * 4;
+    const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1], n = seg1 - seg0;
+    constexpr int ROWS = RPT * SRL;
+    const int nslab = (n + ROWS - 1) / ROWS;
+    float* ss = a.segsum + (int64_t)s * 2 * a.C + c;
+    if (n <= 0) {
+        if (j == 0 && rl == 0) { st4(ss, zero4()); st4(ss + a.C, zero4()); }
+        return;
+    }
+    if (j >= nslab) return;
+    const int r0 = seg0 + j * ROWS, r1 = min(r0 + ROWS, seg1);
+    float4 mean, rstd;
+    stats_for(a, s, c, &mean, &rstd);
+    const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
+    float4 xh[RPT], ga[RPT];
+    float4 a1 = zero4(), a2 = zero4();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        xh[i] = zero4();
+        ga[i] = zero4();
+        if (r < r1) {
+            const int64_t off = (int64_t)r * a.C + c;
+            xh[i] = mul4(sub4(load_u(a, off), mean), rstd);
+            ga[i] = mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
+            a1 = add4(a1, ga[i]);
+            a2 = add4(a2, mul4(ga[i], xh[i]));
+        }
+    }
+    a1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
+    a2 = colsum_t<SRL, SCQ>(a2, sh, rl, cq);
+    if (rl == 0) {
+        float* p = a.part + ((int64_t)(s * a.slabs + j) * 2) * a.C + c;
+        st4x2_agent(p, a1, p + a.C, a2);
+    }
+    slab_meet(a, s, nslab);
+    a1 = zero4();
+    a2 = zero4();
+    if (rl < nslab) {                                        // row lane rl holds slab rl's partial sums
+        const float* p = a.part + ((int64_t)(s * a.slabs + rl) * 2) * a.C + c;
+        ld4x2_agent(p, p + a.C, &a1, &a2);
+    }
+    slab_leave(a, s, nslab);
+    const float4 s1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
+    const float4 s2 = colsum_t<SRL, SCQ>(a2, sh, rl, cq);
+    if (j == 0 && rl == 0) {
+        st4(ss, s1);
+        st4(ss + a.C, s2);
+        if (a.pg_beta) st4(a.pg_beta + c, s1);
+        if (a.pg_gamma) st4(a.pg_gamma + c, s2);
+    }
+    const float inv_n = 1.f / n;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = r0 + rl + i * SRL;
+        if (r < r1) st4(a.y + (int64_t)r * a.C + c, bwd_input(a, ga[i], xh[i], s1, s2, gam, rstd, inv_n));
+    }
+}
+
 // g_gamma[grp] = sum over the group's segments of sum(g*xhat); g_beta likewise.  blockIdx.y = group;
 // outputs land at base + out_off[grp] (offsets into the per-task gradient buffer).
 struct BnGroups {
@@ -453,6 +706,14 @@ __global__ __launch_bounds__(THREADS) void bn_param_grad_kernel(const float* __r
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 int chunks_for(int64_t max_seg_rows) { return (int)((max_seg_rows + CHUNK - 1) / CHUNK); }
+int slabs_for(int64_t max_seg_rows) { return (int)((max_seg_rows + SLAB_ROWS - 1) / SLAB_ROWS); }
+// partial slots per segment the workspace holds: the slab regime's 128-row slabs where it may run, 256-row chunks beyond
+int parts_for(int64_t max_seg_rows) { return max_seg_rows <= SLAB_MAX ? slabs_for(max_seg_rows) : chunks_for(max_seg_rows); }
+int64_t slab_sync_words(int C, int S) { return 2 + 2 * (int64_t)S * (C / SCOLS); }
+// the slab regime runs when the caller passed rendezvous words (enough of them) and the longest segment is in its range
+bool slab_regime(const gmp_bn_config* cfg, int64_t max_seg_rows, int C, int S) {
+    return cfg->sync && max_seg_rows > SHORT_MAX && max_seg_rows <= SLAB_MAX && (int64_t)cfg->sync_words >= slab_sync_words(C, S);
+}
 
 int common_check(const char* who, int64_t rows, int C, int S, int64_t max_seg_rows, const gmp_bn_config* cfg) {
     if (!cfg) return gmp::fail(GMP_ERR_ARG, "%s: null config", who);
@@ -469,9 +730,11 @@ int common_check(const char* who, int64_t rows, int C, int S, int64_t max_seg_ro
 extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max_seg_rows) {
     (void)rows;
     size_t b = al((size_t)S * 2 * C * sizeof(float));
-    if (max_seg_rows > SHORT_MAX) b += al((size_t)S * chunks_for(max_seg_rows) * 2 * C * sizeof(float));
+    if (max_seg_rows > SHORT_MAX) b += al((size_t)S * parts_for(max_seg_rows) * 2 * C * sizeof(float));
     return b + 256;
 }
+
+extern "C" size_t gmp_bn_sync_bytes(int C, int S) { return (size_t)slab_sync_words(C, S) * sizeof(int32_t); }
 
 // WIDE: 64 row lanes (512 threads) and half the rows per thread for the same (segment, 32 columns) tile.  The backward kernel
 // at 16 rows per thread needs 204 VGPRs: beside the resident blocks of the weight-gradient GEMM it runs next to in the step
@@ -509,7 +772,12 @@ extern "C" int gmp_bn_fwd(const float* x, const float* residual, const int32_t* 
     a.part = (float*)((char*)ws + al((size_t)S * 2 * C * sizeof(float)));
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
-    if (max_seg_rows <= SHORT_MAX) {
+    if (slab_regime(cfg, max_seg_rows, C, S)) {
+        a.slabs = slabs_for(max_seg_rows);
+        a.fold_running = cfg->training && running_mean && running_var && S == 1 && !seg_group;
+        hipLaunchKernelGGL(bn_fwd_slab_kernel<SLAB_RPT>, dim3(S * a.slabs, C / SCOLS), blk, 0, st, a);
+        if (a.fold_running) return gmp::check_launch("bn_fwd_slab_kernel");
+    } else if (max_seg_rows <= SHORT_MAX) {
         GMP_BN_SHORT_LAUNCH(bn_fwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, true);
     } else if (max_seg_rows <= MID_MAX) {
         GMP_BN_MID_LAUNCH(bn_fwd_short_kernel, max_seg_rows, S, C, st, a);
@@ -658,7 +926,15 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
     a.part = (float*)((char*)ws + al((size_t)S * 2 * C * sizeof(float)));
     a.chunks = chunks_for(max_seg_rows);
     const dim3 blk(THREADS);
-    if (max_seg_rows <= SHORT_MAX) {
+    if (slab_regime(cfg, max_seg_rows, C, S)) {
+        a.slabs = slabs_for(max_seg_rows);
+        if (G == 1 && S == 1 && grp_seg_ptr_host[0] == 0 && grp_seg_ptr_host[1] == 1) {   // one segment = one group: no reduction left to do
+            a.pg_gamma = g_gamma + (grp_off_gamma_host ? grp_off_gamma_host[0] : 0);
+            a.pg_beta = g_beta + (grp_off_beta_host ? grp_off_beta_host[0] : 0);
+            G = 0;
+        }
+        hipLaunchKernelGGL(bn_bwd_slab_kernel<SLAB_RPT>, dim3(S * a.slabs, C / SCOLS), blk, 0, st, a);
+    } else if (max_seg_rows <= SHORT_MAX) {
         GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, true);
     } else if (max_seg_rows <= MID_MAX) {
         GMP_BN_MID_LAUNCH(bn_bwd_short_kernel, max_seg_rows, S, C, st, a);

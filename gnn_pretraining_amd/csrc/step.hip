@@ -91,7 +91,7 @@ bool phase_timing() {
 }
 
 gmp_bn_config bn_cfg(const gmp_step_desc& d, bool relu, bool dropout, uint32_t site) {
-    gmp_bn_config c;
+    gmp_bn_config c{};
     c.training = d.training;
     c.relu = relu;
     c.eps = 1e-5f;

@@ -79,6 +79,10 @@ class NodeClassificationEngine:
         self._graph, self._graph_key, self._graph_step, self._graph_seen = None, None, -1, None
         self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
+        # rendezvous words of the BatchNorm slab form (gmp_bn_config.sync: the graph's 2,708 rows as 128-row slabs over the whole chip, one
+        # launch); every BatchNorm of the step runs on the main stream, so one buffer serves them all.  GMP_BN_SLABS=0: one workgroup per strip
+        self.bn_sync = (torch.zeros(self.lib.gmp_bn_sync_bytes(2 * H, 1) // 4, dtype=torch.int32, device=dev)
+                        if _os.environ.get("GMP_BN_SLABS", "1") != "0" else None)
         self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
         self.loss_ws = torch.empty(self.lib.gmp_loss_workspace_bytes(N * H), dtype=torch.uint8, device=dev)
         self.loss_sum, self.g_scale = torch.zeros(1, device=dev), torch.ones(1, device=dev)
@@ -141,9 +145,10 @@ class NodeClassificationEngine:
         """Dropout seed of a launch = seed * 1000003 + step number; in a captured step the step number comes from the device word."""
         p = self.dropout_p if (dropout and self.model.training) else 0.0
         base = self.seed * 1000003
+        sync = (self.bn_sync.data_ptr(), self.bn_sync.numel()) if self.bn_sync is not None else (None, 0)
         if self._seed_dev:
-            return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, base & (2 ** 64 - 1), site, self._seed_dev)
-        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (base + self.step_count) & (2 ** 64 - 1), site, None)
+            return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, base & (2 ** 64 - 1), site, self._seed_dev, *sync)
+        return L.BnConfig(int(self.model.training), int(relu), 1e-5, 0.1, p, (base + self.step_count) & (2 ** 64 - 1), site, None, *sync)
 
     _seed_dev = None
 

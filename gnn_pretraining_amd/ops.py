@@ -224,8 +224,18 @@ def colsum(A: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 
 
 def make_bn_config(training: bool, relu: bool, dropout_p: float = 0.0, seed: int = 0, stream_id: int = 0,
-                   eps: float = 1e-5, momentum: float = 0.1) -> L.BnConfig:
-    return L.BnConfig(int(training), int(relu), eps, momentum, float(dropout_p), seed & (2 ** 64 - 1), stream_id)
+                   eps: float = 1e-5, momentum: float = 0.1, sync: Optional[Tensor] = None) -> L.BnConfig:
+    """sync: zero-filled int32 device tensor of bn_sync_words(channels, segments) words (gmp_bn_config.sync): segments of 1,025-4,096
+    rows then run as 128-row slabs over the whole chip.  The caller keeps the tensor alive while launches that got it are in flight."""
+    if sync is None:
+        return L.BnConfig(int(training), int(relu), eps, momentum, float(dropout_p), seed & (2 ** 64 - 1), stream_id)
+    _need(sync, torch.int32, "sync", 1)
+    return L.BnConfig(int(training), int(relu), eps, momentum, float(dropout_p), seed & (2 ** 64 - 1), stream_id, None, sync.data_ptr(),
+                      sync.numel())
+
+
+def bn_sync_words(channels: int, num_segments: int) -> int:
+    return L.lib().gmp_bn_sync_bytes(channels, num_segments) // 4
 
 
 def bn_fwd(x: Tensor, residual: Optional[Tensor], seg_ptr: Tensor, max_seg_rows: int, gamma: Tensor, beta: Tensor,

@@ -190,9 +190,15 @@ typedef struct {
     uint32_t stream_id;  /* distinct per dropout site */
     const uint64_t* seed_dev;  /* NULL, or a DEVICE word added to `seed` when the kernel runs: a launch captured in a hipGraph draws fresh
                                   masks on every replay (the caller bumps the word between replays, gmp_counter_add) */
+    int32_t* sync;       /* NULL, or DEVICE rendezvous words (gmp_bn_sync_bytes), zero-filled by the caller ONCE and private to the stream the
+                            call runs on: segments of 1,025..4,096 rows (the Cora graph) are then cut into 128-row slabs over the whole chip
+                            that meet through these words inside ONE launch, instead of one workgroup per (segment, column strip).  Calls
+                            leave the words zero; sync[0] != 0 afterwards = a meeting timed out (the words were not zero) */
+    uint32_t sync_words; /* int32 words behind `sync`; fewer than gmp_bn_sync_bytes asks for = the slab form is not used */
 } gmp_bn_config;
 
 size_t gmp_bn_workspace_bytes(int64_t rows, int channels, int num_segments, int64_t max_seg_rows);
+size_t gmp_bn_sync_bytes(int channels, int num_segments);
 /* seg_group: NULL, or device int32 [S] giving each segment's PARAMETER GROUP: gamma, beta and the running
  * statistics are then [groups][C] arrays (the four per-domain input encoders stacked in one launch). */
 int gmp_bn_fwd(const float* x, const float* residual, const int32_t* seg_ptr, const int32_t* seg_group,

@@ -249,7 +249,8 @@ def _bn_oracle(x, res, seg, gamma, beta, rm, rv, training, relu):
                                                  ([0, 2708], 256, True, True), ([0, 1500, 1500 + 700], 64, False, False),
                                                  ([0, 2, 5], 128, True, False), ([0, 3500, 3500 + 1100], 128, True, True)])   # short / medium / chunked regimes
 @pytest.mark.parametrize("training", [True, False])
-def test_bn_fwd_bwd(seg, C, relu, with_res, training):
+@pytest.mark.parametrize("slabs", [False, True])     # True: rendezvous words given, segments of 1,025-4,096 rows run as 128-row slabs
+def test_bn_fwd_bwd(seg, C, relu, with_res, training, slabs):
     gen = torch.Generator().manual_seed(sum(seg) + C)
     rows = seg[-1]
     x = torch.randn(rows, C, generator=gen) * 2 + 0.5
@@ -269,7 +270,8 @@ def test_bn_fwd_bwd(seg, C, relu, with_res, training):
     segd = torch.tensor(seg, dtype=torch.int32, device=DEV)
     mx = max(b - a for a, b in zip(seg[:-1], seg[1:]))
     rmd, rvd = d(rm0.clone()), d(rv0.clone())
-    cfg = ops.make_bn_config(training, relu)
+    sync = torch.zeros(ops.bn_sync_words(C, len(seg) - 1), dtype=torch.int32, device=DEV) if slabs else None
+    cfg = ops.make_bn_config(training, relu, sync=sync)
     y, sm, sr = ops.bn_fwd(d(x), d(res), segd, mx, d(gamma), d(beta), rmd, rvd, cfg)
     close(y, want, what="bn fwd")
     close(rmd, rm, what="running_mean"); close(rvd, rv, what="running_var")
@@ -278,6 +280,33 @@ def test_bn_fwd_bwd(seg, C, relu, with_res, training):
     if with_res:
         close(gu, rr.grad, rtol=2e-4, what="bn g_residual")
     close(gg[0], gr.grad, rtol=2e-4, what="bn g_gamma"); close(gb[0], br.grad, rtol=2e-4, what="bn g_beta")
+    if slabs:
+        assert not sync.any().item(), "the slab form leaves its rendezvous words zero (sync[0] != 0: a meeting timed out)"
+
+
+def test_bn_slab_form_draws_the_masks_of_the_strip_form_and_repeats_bitwise():
+    """The Cora-sized segment as 128-row slabs (gmp_bn_config.sync) against one workgroup per column strip: same dropout mask (keyed by
+    element), statistics equal to rounding, and the slab form's own results bit-identical from call to call (fixed combination order)."""
+    gen = torch.Generator().manual_seed(77)
+    rows, C = 2708, 512
+    x, gy = (torch.randn(rows, C, generator=gen) * 3 + 1).to(DEV), torch.randn(rows, C, generator=gen).to(DEV)
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    segd = torch.tensor([0, rows], dtype=torch.int32, device=DEV)
+    sync = torch.zeros(ops.bn_sync_words(C, 1), dtype=torch.int32, device=DEV)
+    outs = []
+    for sy in (None, sync, sync):
+        cfg = ops.make_bn_config(True, True, dropout_p=0.2, seed=99, stream_id=5, sync=sy)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y, sm, sr = ops.bn_fwd(x, None, segd, rows, gamma, beta, rm, rv, cfg)
+        gu, gg, gb = ops.bn_bwd(gy, x, None, segd, rows, gamma, beta, rm, rv, sm, sr, cfg)
+        outs.append((y, sm, sr, rm, rv, gu, gg, gb))
+    strip, slab, again = outs
+    for a, b in zip(slab, again):
+        assert torch.equal(a, b)
+    assert ((strip[0] != 0) != (slab[0] != 0)).sum().item() <= 4          # same dropout mask; a ReLU edge may flip at rounding level
+    for a, b, what in zip(strip, slab, ("y", "mean", "rstd", "running_mean", "running_var", "g_u", "g_gamma", "g_beta")):
+        close(a, b, rtol=1e-5, what="slab vs strip " + what)
+    assert not sync.any().item()
 
 
 def test_bn_param_grad_groups_and_dropout_consistency():
