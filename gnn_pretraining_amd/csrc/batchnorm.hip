@@ -439,60 +439,68 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_long_kernel(BnArgs a) {
 // Segments of SHORT_MAX < rows <= SLAB_MAX when the caller passes rendezvous words (gmp_bn_config.sync): the 2,708-node Cora graph is
 // ONE segment, and a (segment, column strip) tile owned by one workgroup is bound by ONE CU's bandwidth (18.5 us forward, 34 us
 // backward for 5.5 MB, r03 trace; the three chunked launches were no faster).  Here the segment's rows are cut into slabs of
-// SLAB_ROWS; workgroup (slab, strip) keeps its 128 x 32 tile in registers, publishes its partial statistics, MEETS the other slabs
-// of its (segment, strip) through a counter, combines all partials in a fixed order (so every workgroup derives bit-identical
-// statistics, whatever the arrival order) and applies -- one read and one write per element on the whole chip, one launch.
-// Progress: the slabs of a group are consecutive in dispatch order (slab = fastest grid index), so a group's workgroups become
-// resident together as soon as earlier groups retire; a meeting that lasts SLAB_TIMEOUT (words not zeroed by the caller) gives up
-// and raises sync[0].  The last workgroup to leave a group resets its two words: calls leave the buffer as they found it.
+// SLAB_ROWS; workgroup (slab, strip) keeps its 128 x 32 tile in registers, publishes its partial statistics, collects the partials of the
+// other slabs of its (segment, strip), combines all of them in a fixed order (so every workgroup derives bit-identical statistics,
+// whatever the arrival order) and applies -- one read and one write per element on the whole chip, one launch.
+// Progress: nobody waits before having published, and the slabs of a group are consecutive in dispatch order (slab = fastest grid
+// index), so a group's workgroups become resident together as soon as earlier groups retire; a wait that lasts SLAB_TIMEOUT (the
+// words were not zeroed, or two streams share them) gives up and raises sync[0].
 constexpr int SLAB_RPT = 4, SLAB_ROWS = SLAB_RPT * SRL, SLAB_MAX = SRL * SLAB_ROWS;    // 128-row slabs, at most 32 of them (one per row lane)
 constexpr unsigned long long SLAB_TIMEOUT_TICKS = 200000000ull;                         // 2 s of the 100 MHz wall clock
 
-__device__ __forceinline__ int* slab_words(const BnArgs& a, int s) { return a.cfg.sync + 2 + 2 * (s * (int)gridDim.y + (int)blockIdx.y); }
-
-// Partials cross workgroups (and XCDs, each with its own L2) inside one launch: written and read with agent-scope (`sc1`) accesses, NOT behind
-// agent-scope fences -- with `__threadfence()` on both sides of the meeting (352 workgroups writing back and invalidating caches twice each)
-// the launch was 25 us SLOWER than the form it replaces.
-// Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility): every byte stored `sc1` by 16-byte stores that fill whole 128-byte lines
-// (the eight column quads of row lane 0 = eight lanes of wave 0), the storing wave drains its stores, a workgroup barrier, ONE lane adds to the
-// group's counter; the reader polls the counter with `sc1` loads, a workgroup barrier, then `sc1` 16-byte loads.  (Scalar `sc1` stores are
-// one fabric write each: as `__hip_atomic_store` per float the launch took 17 us.)
+// Hand-off = tagged granules (MI355X_MICROARCH.md, persistent-kernel price list, "handoff-1to1"): a partial travels as 8-byte {value, tag}
+// pairs written by 16-byte `sc1` (write-through, device-coherent) stores; a reader polls the granules it needs with `sc1` loads until all
+// carry this launch's tag.  No flag, no counter, no barrier on the path: store -> visible -> seen is one hop (≈2 us of a 9 us launch), where
+// {drain stores, barrier, counter add, poll the counter, barrier, load} cost 7.7 us, and `__threadfence()` on both sides 33.
+// tag = generation + 1; the generation word sync[1] advances when the LAST workgroup of a launch has left (sync[2] counts them), so
+// granules of earlier launches, whatever their shapes, never carry the current tag (the buffer starts zero-filled: tag >= 1).
+constexpr int SYNC_HDR = 64;                                                               // int32 words: [0] error, [1] generation, [2] departures
 typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st4x2_agent(float* p, float4 v, float* q, float4 w) {      // two 16-byte write-through stores, drained
-    const f4v a = {v.x, v.y, v.z, v.w}, b = {w.x, w.y, w.z, w.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(a), "v"(q), "v"(b) : "memory");
+__device__ __forceinline__ float* slab_granules(const BnArgs& a, int s, int slab, int stat, int c) {   // float pairs [S][32][2][C]
+    return reinterpret_cast<float*>(a.cfg.sync + SYNC_HDR) + 2 * ((((int64_t)s * SRL + slab) * 2 + stat) * a.C + c);
 }
-__device__ __forceinline__ void ld4x2_agent(const float* p, const float* q, float4* v, float4* w) {   // two 16-byte L1-bypassing loads, waited
-    f4v a, b;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(p), "v"(q) : "memory");
-    *v = make_float4(a.x, a.y, a.z, a.w);
-    *w = make_float4(b.x, b.y, b.z, b.w);
+__device__ __forceinline__ unsigned slab_tag(const BnArgs& a) {
+    return (unsigned)__hip_atomic_load(a.cfg.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 }
-
-__device__ __forceinline__ void slab_meet(const BnArgs& a, int s, int nslab) {
-    __syncthreads();                   // (s_waitcnt vmcnt(0) + barrier) every partial store of this workgroup has been acknowledged
-    if (threadIdx.x == 0) {
-        int* w = slab_words(a, s);
-        __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        for (unsigned i = 1;; ++i) {   // exit every workgroup reaches: all slabs arrived, or the wall clock says they are not coming
-            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nslab) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((i & 1023u) == 0 && wall_clock64() - t0 > SLAB_TIMEOUT_TICKS) {
-                atomicOr(a.cfg.sync, 1);
-                break;
-            }
+// lane (row lane 0, column quad cq) publishes its four columns of both statistics: 4 x 16 bytes, fire and forget
+__device__ __forceinline__ void slab_publish(const BnArgs& a, int s, int j, int c, float4 v0, float4 v1, unsigned tag) {
+    const float t = __uint_as_float(tag);
+    float* p0 = slab_granules(a, s, j, 0, c);
+    float* p1 = slab_granules(a, s, j, 1, c);
+    const f4v x0 = {v0.x, t, v0.y, t}, x1 = {v0.z, t, v0.w, t}, y0 = {v1.x, t, v1.y, t}, y1 = {v1.z, t, v1.w, t};
+    asm volatile("global_store_dwordx4 %0, %2, off sc1\n\tglobal_store_dwordx4 %0, %3, off offset:16 sc1\n\t"
+                 "global_store_dwordx4 %1, %4, off sc1\n\tglobal_store_dwordx4 %1, %5, off offset:16 sc1"
+                 ::"v"(p0), "v"(p1), "v"(x0), "v"(x1), "v"(y0), "v"(y1) : "memory");
+}
+// lane (row lane = slab, column quad) waits for that slab's granules; an exit every lane reaches: all tags seen, or the wall clock
+__device__ __forceinline__ void slab_collect(const BnArgs& a, int s, int slab, int c, unsigned tag, float4* v0, float4* v1) {
+    const float* p0 = slab_granules(a, s, slab, 0, c);
+    const float* p1 = slab_granules(a, s, slab, 1, c);
+    const unsigned long long t0 = wall_clock64();
+    f4v x0, x1, y0, y1;
+    for (unsigned i = 1;; ++i) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1) : "v"(p0), "v"(p1) : "memory");
+        const bool ok = __float_as_uint(x0.y) == tag && __float_as_uint(x0.w) == tag && __float_as_uint(x1.y) == tag && __float_as_uint(x1.w) == tag &&
+                        __float_as_uint(y0.y) == tag && __float_as_uint(y0.w) == tag && __float_as_uint(y1.y) == tag && __float_as_uint(y1.w) == tag;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((i & 255u) == 0 && wall_clock64() - t0 > SLAB_TIMEOUT_TICKS) {
+            atomicOr(a.cfg.sync, 1);
+            break;
         }
     }
-    __syncthreads();
+    *v0 = make_float4(x0.x, x0.z, x1.x, x1.z);
+    *v1 = make_float4(y0.x, y0.z, y1.x, y1.z);
 }
-
-__device__ __forceinline__ void slab_leave(const BnArgs& a, int s, int nslab) {
+// every workgroup of the launch, when it has read what it needs (callers put a workgroup barrier in front): the last one advances the generation
+__device__ __forceinline__ void slab_depart(const BnArgs& a, unsigned tag) {
     if (threadIdx.x == 0) {
-        int* w = slab_words(a, s);
-        if (__hip_atomic_fetch_add(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslab - 1) {   // everybody is past the meeting
-            __hip_atomic_store(w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(w + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int total = (int)(gridDim.x * gridDim.y);
+        if (__hip_atomic_fetch_add(a.cfg.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+            __hip_atomic_store(a.cfg.sync + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.cfg.sync + 1, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -527,7 +535,11 @@ __global__ __launch_bounds__(THREADS) void bn_fwd_slab_kernel(BnArgs a) {
     const int seg0 = a.seg_ptr[s], seg1 = a.seg_ptr[s + 1], n = seg1 - seg0;
     constexpr int ROWS = RPT * SRL;
     const int nslab = (n + ROWS - 1) / ROWS;
-    if (j >= nslab) return;                                  // block-uniform: slabs past the segment's end take no part
+    const unsigned tag = a.cfg.training ? slab_tag(a) : 0u;
+    if (j >= nslab) {                                        // block-uniform: slabs past the segment's end have nothing to add
+        if (a.cfg.training) slab_depart(a, tag);
+        return;
+    }
     const int r0 = seg0 + j * ROWS, r1 = min(r0 + ROWS, seg1);
     float4 u[RPT];
 #pragma unroll
@@ -549,20 +561,12 @@ __global__ __launch_bounds__(THREADS) void bn_fwd_slab_kernel(BnArgs a) {
                 acc = add4(acc, mul4(d, d));
             }
         const float4 lm2 = colsum_t<SRL, SCQ>(acc, sh, rl, cq);
-        if (rl == 0) {
-            float* p = a.part + ((int64_t)(s * a.slabs + j) * 2) * a.C + c;
-            st4x2_agent(p, lmean, p + a.C, lm2);
-        }
-        slab_meet(a, s, nslab);
-        Mom m;                                               // row lane rl holds slab rl's partial
+        if (rl == 0) slab_publish(a, s, j, c, lmean, lm2, tag);
+        Mom m;                                               // row lane rl collects slab rl's partial
         m.n = rl < nslab ? (float)min(ROWS, n - rl * ROWS) : 0.f;
         m.mean = zero4();
         m.m2 = zero4();
-        if (rl < nslab) {
-            const float* p = a.part + ((int64_t)(s * a.slabs + rl) * 2) * a.C + c;
-            ld4x2_agent(p, p + a.C, &m.mean, &m.m2);
-        }
-        slab_leave(a, s, nslab);
+        if (rl < nslab) slab_collect(a, s, rl, c, tag, &m.mean, &m.m2);
 #pragma unroll
         for (int o = SCQ; o < 64; o <<= 1) {                 // the eight row lanes of a wave; (lower lane, higher lane) whoever computes
             Mom q;
@@ -577,6 +581,7 @@ __global__ __launch_bounds__(THREADS) void bn_fwd_slab_kernel(BnArgs a) {
             if (cq == 0) shn[rl >> 3] = m.n;
         }
         __syncthreads();
+        slab_depart(a, tag);                                 // (behind the barrier: every lane of this workgroup has collected)
         m.n = shn[0];
         m.mean = shm[0][0][cq];
         m.m2 = shm[0][1][cq];
@@ -630,11 +635,12 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_slab_kernel(BnArgs a) {
     constexpr int ROWS = RPT * SRL;
     const int nslab = (n + ROWS - 1) / ROWS;
     float* ss = a.segsum + (int64_t)s * 2 * a.C + c;
-    if (n <= 0) {
-        if (j == 0 && rl == 0) { st4(ss, zero4()); st4(ss + a.C, zero4()); }
+    const unsigned tag = slab_tag(a);
+    if (n <= 0 || j >= nslab) {
+        if (n <= 0 && j == 0 && rl == 0) { st4(ss, zero4()); st4(ss + a.C, zero4()); }
+        slab_depart(a, tag);
         return;
     }
-    if (j >= nslab) return;
     const int r0 = seg0 + j * ROWS, r1 = min(r0 + ROWS, seg1);
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
@@ -656,20 +662,13 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_slab_kernel(BnArgs a) {
     }
     a1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
     a2 = colsum_t<SRL, SCQ>(a2, sh, rl, cq);
-    if (rl == 0) {
-        float* p = a.part + ((int64_t)(s * a.slabs + j) * 2) * a.C + c;
-        st4x2_agent(p, a1, p + a.C, a2);
-    }
-    slab_meet(a, s, nslab);
+    if (rl == 0) slab_publish(a, s, j, c, a1, a2, tag);
     a1 = zero4();
     a2 = zero4();
-    if (rl < nslab) {                                        // row lane rl holds slab rl's partial sums
-        const float* p = a.part + ((int64_t)(s * a.slabs + rl) * 2) * a.C + c;
-        ld4x2_agent(p, p + a.C, &a1, &a2);
-    }
-    slab_leave(a, s, nslab);
+    if (rl < nslab) slab_collect(a, s, rl, c, tag, &a1, &a2);   // row lane rl collects slab rl's partial sums
     const float4 s1 = colsum_t<SRL, SCQ>(a1, sh, rl, cq);
     const float4 s2 = colsum_t<SRL, SCQ>(a2, sh, rl, cq);
+    slab_depart(a, tag);                                     // (behind colsum_t's barriers: every lane of this workgroup has collected)
     if (j == 0 && rl == 0) {
         st4(ss, s1);
         st4(ss + a.C, s2);
@@ -707,9 +706,7 @@ __global__ __launch_bounds__(THREADS) void bn_param_grad_kernel(const float* __r
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 int chunks_for(int64_t max_seg_rows) { return (int)((max_seg_rows + CHUNK - 1) / CHUNK); }
 int slabs_for(int64_t max_seg_rows) { return (int)((max_seg_rows + SLAB_ROWS - 1) / SLAB_ROWS); }
-// partial slots per segment the workspace holds: the slab regime's 128-row slabs where it may run, 256-row chunks beyond
-int parts_for(int64_t max_seg_rows) { return max_seg_rows <= SLAB_MAX ? slabs_for(max_seg_rows) : chunks_for(max_seg_rows); }
-int64_t slab_sync_words(int C, int S) { return 2 + 2 * (int64_t)S * (C / SCOLS); }
+int64_t slab_sync_words(int C, int S) { return SYNC_HDR + (int64_t)S * SRL * 2 * C * 2; }   // header + granules [S][32 slabs][2][C] of 8 bytes
 // the slab regime runs when the caller passed rendezvous words (enough of them) and the longest segment is in its range
 bool slab_regime(const gmp_bn_config* cfg, int64_t max_seg_rows, int C, int S) {
     return cfg->sync && max_seg_rows > SHORT_MAX && max_seg_rows <= SLAB_MAX && (int64_t)cfg->sync_words >= slab_sync_words(C, S);
@@ -730,7 +727,7 @@ int common_check(const char* who, int64_t rows, int C, int S, int64_t max_seg_ro
 extern "C" size_t gmp_bn_workspace_bytes(int64_t rows, int C, int S, int64_t max_seg_rows) {
     (void)rows;
     size_t b = al((size_t)S * 2 * C * sizeof(float));
-    if (max_seg_rows > SHORT_MAX) b += al((size_t)S * parts_for(max_seg_rows) * 2 * C * sizeof(float));
+    if (max_seg_rows > SHORT_MAX) b += al((size_t)S * chunks_for(max_seg_rows) * 2 * C * sizeof(float));
     return b + 256;
 }
 

@@ -190,10 +190,10 @@ typedef struct {
     uint32_t stream_id;  /* distinct per dropout site */
     const uint64_t* seed_dev;  /* NULL, or a DEVICE word added to `seed` when the kernel runs: a launch captured in a hipGraph draws fresh
                                   masks on every replay (the caller bumps the word between replays, gmp_counter_add) */
-    int32_t* sync;       /* NULL, or DEVICE rendezvous words (gmp_bn_sync_bytes), zero-filled by the caller ONCE and private to the stream the
+    int32_t* sync;       /* NULL, or a DEVICE buffer of gmp_bn_sync_bytes, zero-filled by the caller ONCE and private to the stream the
                             call runs on: segments of 1,025..4,096 rows (the Cora graph) are then cut into 128-row slabs over the whole chip
-                            that meet through these words inside ONE launch, instead of one workgroup per (segment, column strip).  Calls
-                            leave the words zero; sync[0] != 0 afterwards = a meeting timed out (the words were not zero) */
+                            that exchange their partial statistics through this buffer inside ONE launch, instead of one workgroup per
+                            (segment, column strip).  sync[0] != 0 afterwards = a wait timed out (buffer not zeroed, or shared by streams) */
     uint32_t sync_words; /* int32 words behind `sync`; fewer than gmp_bn_sync_bytes asks for = the slab form is not used */
 } gmp_bn_config;
 

@@ -281,7 +281,7 @@ def test_bn_fwd_bwd(seg, C, relu, with_res, training, slabs):
         close(gu, rr.grad, rtol=2e-4, what="bn g_residual")
     close(gg[0], gr.grad, rtol=2e-4, what="bn g_gamma"); close(gb[0], br.grad, rtol=2e-4, what="bn g_beta")
     if slabs:
-        assert not sync.any().item(), "the slab form leaves its rendezvous words zero (sync[0] != 0: a meeting timed out)"
+        assert sync[0].item() == 0 and sync[2].item() == 0, "sync[0] != 0: a wait timed out; sync[2] != 0: a workgroup never left"
 
 
 def test_bn_slab_form_draws_the_masks_of_the_strip_form_and_repeats_bitwise():
@@ -306,7 +306,7 @@ def test_bn_slab_form_draws_the_masks_of_the_strip_form_and_repeats_bitwise():
     assert ((strip[0] != 0) != (slab[0] != 0)).sum().item() <= 4          # same dropout mask; a ReLU edge may flip at rounding level
     for a, b, what in zip(strip, slab, ("y", "mean", "rstd", "running_mean", "running_var", "g_u", "g_gamma", "g_beta")):
         close(a, b, rtol=1e-5, what="slab vs strip " + what)
-    assert not sync.any().item()
+    assert sync[0].item() == 0 and sync[1].item() == 4 and sync[2].item() == 0     # no time-out; four launches = four generations; all left
 
 
 def test_bn_param_grad_groups_and_dropout_consistency():
