@@ -42,14 +42,22 @@ enum {
     F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
     F_FWD_FORK = 39,                   // main -> the second forward stream: encoders done (split forward)
     F_FWD_JOIN = 40,                   // [2] the other forward streams -> main: their row range of the stacked forward is done
+    F_WG1_L = 42,                      // [layer] second weight-gradient stream -> exchange stream: the layer's W1 / BatchNorm-1 gradients are final
+    F_WG1_DONE = 47,                   // second weight-gradient stream -> main: everything it did for this step is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
     int32_t* flags = nullptr;
     int epoch = 0;
     uint64_t head_params_mask = 0;
+    bool wg1 = false;                  // the W1 weight-gradient GEMMs ran on a stream of their own (F_WG1_*)
 };
 SyncState g_sync;
+
+bool wg1_enabled() {
+    static const bool on = !(getenv("GMP_STEP_WG1") && atoi(getenv("GMP_STEP_WG1")) == 0);
+    return on;
+}
 
 hipEvent_t* events() {   // one process drives one engine: a small static pool of timing-free events
     static hipEvent_t ev[NEV];
@@ -348,6 +356,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     g_sync.flags = gates ? d.sync_flags : nullptr;
     g_sync.epoch = d.epoch;
     g_sync.head_params_mask = 0;
+    g_sync.wg1 = false;
     auto signal = [&](int flag, hipEvent_t e, hipStream_t s) -> int {
         if (gates) return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
         (void)hipEventRecord(e, s);
@@ -572,11 +581,28 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // the event has long fired by the time the packet is reached -- scripts/diag_blocked_queues.py -- and the host runs ahead.)
     // Without them: two alternating copies, guarded by event waits two layers later.
     // main's encoder backward and aux's grouped weight-gradient GEMMs each get half of gemm_ws (no join between them)
-    const size_t ws_half = per_layer ? (d.gemm_ws_bytes / 2) & ~(size_t)255 : 0;
+    // Two weight-gradient streams: per layer aux carries dW2 (+ the BatchNorm-2 sums, the eps sum), and a head stream -- idle once its head's
+    // weight gradients are out -- carries dW1 (+ the BatchNorm-1 sums).  On ONE stream the two GEMMs, their slice reductions and the sums
+    // add up to ~105 us per layer, as long as main's input-gradient chain (110 us).  Worth 0.8 % (1.409 -> 1.397, 1.417 -> 1.401 ms in two
+    // A/B pairs): the backward is bound by the chip's throughput, not by either chain ("two row ranges").
+    // Needs gates, per-layer buffers and a third of gemm_ws that still holds the slices (GMP_STEP_WG1=0: everything on aux).
+    hipStream_t wg1 = aux;
+    if (lean && aux != main && d.gemm_ws_bytes >= ((size_t)36 << 20) && wg1_enabled())
+        for (int pass = 0; pass < 2 && wg1 == aux; ++pass)       // not the link-prediction head's stream if there is another: its weight gradients take longest
+            for (int ti = 0; ti < T && wg1 == aux; ++ti) {
+                hipStream_t ts = (hipStream_t)task_streams[ti];
+                if (ts != main && ts != aux && (pass == 1 || d.task[ti].kind != GMP_TASK_LP)) wg1 = ts;
+            }
+    gmp_stream_t wg1_ = (gmp_stream_t)wg1;
+    const bool two_wg = wg1 != aux;
+    g_sync.wg1 = two_wg;
+    const size_t ws_part = per_layer ? (d.gemm_ws_bytes / (two_wg ? 3 : 2)) & ~(size_t)255 : 0;
     void* const aux_ws = d.gemm_ws;
-    const size_t aux_ws_bytes = per_layer ? ws_half : d.gemm_ws_bytes;
-    void* const enc_ws = per_layer ? (void*)((char*)d.gemm_ws + ws_half) : d.gemm_ws;
-    const size_t enc_ws_bytes = per_layer ? d.gemm_ws_bytes - ws_half : d.gemm_ws_bytes;
+    const size_t aux_ws_bytes = per_layer ? ws_part : d.gemm_ws_bytes;
+    void* const wg1_ws = two_wg ? (void*)((char*)d.gemm_ws + ws_part) : aux_ws;
+    const size_t wg1_ws_bytes = aux_ws_bytes;
+    void* const enc_ws = per_layer ? (void*)((char*)d.gemm_ws + (two_wg ? 2 : 1) * ws_part) : d.gemm_ws;
+    const size_t enc_ws_bytes = per_layer ? d.gemm_ws_bytes - (two_wg ? 2 : 1) * ws_part : d.gemm_ws_bytes;
     // Training with gates and per-layer buffers: the eps gradient of layer l (a 5 us sum over rowdot that only feeds task_grads)
     // runs on aux at the start of aux's layer l-1 work -- the flag aux waits for there is set after main's aggregation backward
     // of layer l -- from a rowdot buffer per layer; layer 0's goes to aux's tail.
@@ -610,11 +636,12 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         signal_by_gemm(F_BWD_MA + 2 * l + 1, e[2], main);        // g_z1 ready
         GMP_TRY(gemm(GMP_GEMM_NN, gz1, d.flat + L.off_w1, nullptr, ga, N, H, 2 * H, 2 * H, H, H, false, main_));
         GMP_TRY(signal_flush(F_BWD_MA + 2 * l + 1, main));
-        GMP_TRY(await(F_BWD_MA + 2 * l + 1, e[2], aux));
-        if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, aux_));
+        GMP_TRY(await(F_BWD_MA + 2 * l + 1, e[2], wg1));
+        if (split_pg) GMP_TRY(gmp_bn_param_grads(slice(2 + 2 * l), d.S, 2 * H, tg, tg, d.task_seg, L.tg_g1, L.tg_be1, T, wg1_));
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
-                                     1.f, 0, 0, aux_ws, aux_ws_bytes, aux_));
+                                     1.f, 0, 0, wg1_ws, wg1_ws_bytes, wg1_));
         if (!lean) (void)hipEventRecord(e[3], aux);
+        if (two_wg && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_WG1_L + l, d.epoch, wg1_));
         if (gates && d.dp_exchange && !eps_on_aux) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
         float* rowdot = eps_on_aux ? d.rowdot + (size_t)l * N : d.rowdot;
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, rowdot, N, H, main_));
@@ -679,6 +706,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         if (!lean) (void)hipEventRecord(ev[NEV - 1], aux);
     }
     if (lean && aux != main) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_DONE, d.epoch, aux_));
+    if (two_wg) GMP_TRY(gmp_gate_open(d.sync_flags + F_WG1_DONE, d.epoch, wg1_));
     if (d.enc_groups > 0) {
         c = bn_cfg(d, true, true, 1);
         // (its own slice of the BatchNorm scratch: aux may still be reducing layer 0's slices)
@@ -692,6 +720,7 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
                           // statistics) and the heads' weight-gradient GEMMs -- instead of ten event waits at 3-4 us each
         uint64_t mask = g_sync.head_params_mask;
         if (aux != main) mask |= 1ull << F_AUX_DONE;
+        if (two_wg) mask |= 1ull << F_WG1_DONE;
         GMP_TRY(gmp_gate_wait(d.sync_flags, mask, d.epoch, d.sync_flags + F_ERR, main_));
     } else if (defer) {
         (void)hipStreamWaitEvent(main, ev[NEV - 1], 0);   // the next step's forward overwrites the saved batch statistics they read
@@ -714,6 +743,7 @@ extern "C" int gmp_step_wait_grads(int part, gmp_stream_t st_) {
         else {
             const int l = GMP_STEP_LAYERS - part;
             mask = (1ull << (F_AUX_L + l)) | (1ull << (l > 0 ? F_BWD_MA + 2 * (l - 1) : F_L0));
+            if (g_sync.wg1) mask |= 1ull << (F_WG1_L + l);
         }
         return gmp_gate_wait(g_sync.flags, mask, g_sync.epoch, g_sync.flags + F_ERR, st_);
     }

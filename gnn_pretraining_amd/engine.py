@@ -469,7 +469,7 @@ class StepEngine:
         # per-layer g_u / g_z1 of the native executor's backward: aux never holds main back (gnnmp_step.h)
         self.gu_l, self.gz1_l = [f(R, H) for _ in range(Lr)], [f(R, 2 * H) for _ in range(Lr)]
         self.rowdot = f(Lr * R)                              # one slice per backward layer for the native executor (gnnmp_step.h)
-        self.gemm_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs (aux) | encoder backward (main)
+        self.gemm_ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)     # slice partials of the grouped weight-gradient GEMMs (aux | second weight-gradient stream) | encoder backward (main)
         # the task heads are independent of each other: each has its own scratch and they share four streams
         # The runtime multiplexes HIP streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; raising it made the step 2.4x
         # slower), and a per-task stream layout left three task heads serialised on one queue (profiles/README.md).  So:
