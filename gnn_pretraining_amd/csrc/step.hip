@@ -42,15 +42,13 @@ enum {
     F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
     F_FWD_FORK = 39,                   // main -> the second forward stream: encoders done (split forward)
     F_FWD_JOIN = 40,                   // [2] the other forward streams -> main: their row range of the stacked forward is done
-    F_WG1_L = 42,                      // [layer] second weight-gradient stream -> exchange stream: the layer's W1 / BatchNorm-1 gradients are final
-    F_WG1_DONE = 47,                   // second weight-gradient stream -> main: everything it did for this step is done
+    F_WG1_DONE = 42,                   // second weight-gradient stream -> main: everything it did for this step is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
     int32_t* flags = nullptr;
     int epoch = 0;
     uint64_t head_params_mask = 0;
-    bool wg1 = false;                  // the W1 weight-gradient GEMMs ran on a stream of their own (F_WG1_*)
 };
 SyncState g_sync;
 
@@ -356,7 +354,6 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     g_sync.flags = gates ? d.sync_flags : nullptr;
     g_sync.epoch = d.epoch;
     g_sync.head_params_mask = 0;
-    g_sync.wg1 = false;
     auto signal = [&](int flag, hipEvent_t e, hipStream_t s) -> int {
         if (gates) return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
         (void)hipEventRecord(e, s);
@@ -585,9 +582,11 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // weight gradients are out -- carries dW1 (+ the BatchNorm-1 sums).  On ONE stream the two GEMMs, their slice reductions and the sums
     // add up to ~105 us per layer, as long as main's input-gradient chain (110 us).  Worth 0.8 % (1.409 -> 1.397, 1.417 -> 1.401 ms in two
     // A/B pairs): the backward is bound by the chip's throughput, not by either chain ("two row ranges").
-    // Needs gates, per-layer buffers and a third of gemm_ws that still holds the slices (GMP_STEP_WG1=0: everything on aux).
+    // Needs gates, per-layer buffers and a third of gemm_ws that still holds the slices (GMP_STEP_WG1=0: everything on aux).  Not in
+    // data-parallel runs: the exchange lives on a head stream too (engine.py comm_stream) and follows the backward layer by layer through aux's
+    // flags; behind a whole weight-gradient chain in the same in-order queue it would start when the backward ends.
     hipStream_t wg1 = aux;
-    if (lean && aux != main && d.gemm_ws_bytes >= ((size_t)36 << 20) && wg1_enabled())
+    if (lean && aux != main && !d.dp_exchange && d.gemm_ws_bytes >= ((size_t)36 << 20) && wg1_enabled())
         for (int pass = 0; pass < 2 && wg1 == aux; ++pass)       // not the link-prediction head's stream if there is another: its weight gradients take longest
             for (int ti = 0; ti < T && wg1 == aux; ++ti) {
                 hipStream_t ts = (hipStream_t)task_streams[ti];
@@ -595,7 +594,6 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             }
     gmp_stream_t wg1_ = (gmp_stream_t)wg1;
     const bool two_wg = wg1 != aux;
-    g_sync.wg1 = two_wg;
     const size_t ws_part = per_layer ? (d.gemm_ws_bytes / (two_wg ? 3 : 2)) & ~(size_t)255 : 0;
     void* const aux_ws = d.gemm_ws;
     const size_t aux_ws_bytes = per_layer ? ws_part : d.gemm_ws_bytes;
@@ -641,7 +639,6 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_gemm_f32_grouped(GMP_GEMM_TN, gz1, L.a, nullptr, tg, T, d.task_row, nullptr, nullptr, L.tg_w1, tg, L.tg_b1, 2 * H, H, 0, 2 * H, H, H,
                                      1.f, 0, 0, wg1_ws, wg1_ws_bytes, wg1_));
         if (!lean) (void)hipEventRecord(e[3], aux);
-        if (two_wg && d.dp_exchange) GMP_TRY(gmp_gate_open(d.sync_flags + F_WG1_L + l, d.epoch, wg1_));
         if (gates && d.dp_exchange && !eps_on_aux) GMP_TRY(gmp_gate_open(d.sync_flags + F_AUX_L + l, d.epoch, aux_));
         float* rowdot = eps_on_aux ? d.rowdot + (size_t)l * N : d.rowdot;
         GMP_TRY(gmp_gin_aggregate_bwd_ex(ga, d.csr[3], d.csr[4], d.flat + L.off_eps, d.h[l], gu, gcur, rowdot, N, H, main_));
@@ -743,7 +740,6 @@ extern "C" int gmp_step_wait_grads(int part, gmp_stream_t st_) {
         else {
             const int l = GMP_STEP_LAYERS - part;
             mask = (1ull << (F_AUX_L + l)) | (1ull << (l > 0 ? F_BWD_MA + 2 * (l - 1) : F_L0));
-            if (g_sync.wg1) mask |= 1ull << (F_WG1_L + l);
         }
         return gmp_gate_wait(g_sync.flags, mask, g_sync.epoch, g_sync.flags + F_ERR, st_);
     }

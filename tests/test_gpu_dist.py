@@ -96,24 +96,33 @@ def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical(overlap):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, overlap), nprocs=world, join=True)
     # single-rank per-task gradients of the two shards, same replica, no exchange, no update
-    singles = []
-    for r in range(world):
-        model, eng = _build(3, None)
-        inp, gen = _inputs(r, eng)
-        eng.step(inp, gen, apply_update=False)
-        torch.cuda.synchronize()
-        singles.append(eng.task_grads.cpu())
-        has, off, numel, names, P = eng.has_static, eng.off, eng.numel, eng.names, eng.P
+    def single_rank():
+        res = []
+        for r in range(world):
+            model, eng = _build(3, None)
+            inp, gen = _inputs(r, eng)
+            eng.step(inp, gen, apply_update=False)
+            torch.cuda.synchronize()
+            res.append(eng.task_grads.cpu())
+        return res, eng
+    singles, eng = single_rank()
+    has, off, numel, names = eng.has_static, eng.off, eng.numel, eng.names
     mean = (singles[0] + singles[1]) / 2
     got = out[0]["tg"]
-    checked = 0
+    checked, wrong = 0, []
     for k, n in enumerate(names):
         for t in range(got.size(0)):
             if has[k][t]:
                 a, b = got[t, off[n]:off[n] + numel[n]], mean[t, off[n]:off[n] + numel[n]]
                 scale = max(float(b.abs().max()), 1e-6)
-                assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-9, f"{n} task {t}"
+                if float((a - b).abs().max()) > 1e-5 * scale + 1e-9:
+                    wrong.append(f"{n} task {t}: {float((a - b).abs().max()):.2e} of {scale:.2e}")
                 checked += 1
+    if wrong:         # say which side moved: the single-rank reference must at least repeat itself
+        again, _ = single_rank()
+        rep = [torch.equal(a, b) for a, b in zip(singles, again)]
+        raise AssertionError(f"{len(wrong)} of {checked} (task, tensor) pairs off the mean of the single-rank gradients; single-rank runs repeat bitwise: {rep}; "
+                             f"gates {eng.use_gates}; first: {wrong[:6]}")
     assert checked > 100
     assert torch.equal(out[0]["flat"], out[1]["flat"])                      # identical update on both ranks
     assert torch.equal(out[0]["tg"], out[1]["tg"])

@@ -16,7 +16,7 @@ from gnn_pretraining_amd.models import FinetuneGNN, GINBackbone, GINLayer, Input
 from gnn_pretraining_amd.pretrain import pretrain as PT                           # noqa: E402
 from gnn_pretraining_amd.pretrain.tasks import TwoViews                           # noqa: E402
 from oracle import models as OM, tasks as OTk, train as OTr                       # noqa: E402
-from parity_util import assert_close, assert_grad_close, copy_state, set_dropout, to_oracle          # noqa: E402
+from parity_util import assert_close, assert_grad_close, assert_grad_tight, copy_state, set_dropout, to_oracle          # noqa: E402
 
 DEV = torch.device("cuda:0")
 OUT_RTOL = 1e-4
@@ -317,14 +317,33 @@ def test_finetune_node_classification_engine_matches_the_oracle_step():
         g["lr"] *= 100                                   # visible update (lr 1e-4 moves weights by 1e-4 x Adam's unit step)
     eng.lr.mul_(100)
     before = {k: v.clone() for k, v in om.state_dict().items()}
-    lo = torch.nn.functional.cross_entropy(om(to_oracle(Batch.from_data_list([c])))[idx], c.y[idx])
-    oopt.zero_grad(); lo.backward(); oopt.step()
+    # The HIP step first; the oracle then runs with the ReLU gates the engine used (oracle/gates.py), read from the activations the step leaves
+    # behind in call order -- encoder, then the inner and the outer ReLU of each layer -- so that no pre-activation within rounding of zero gates
+    # the two sides differently.  (Without: one flipped unit of one node moves a whole row of a weight gradient; with 140 labelled nodes that
+    # was 26 % of the tensor's largest entry on one box, where the pre-training step's flips stay near 1e-3.)
     eng.step(idx.to(DEV), c.y[idx].to(DEV))
+    torch.cuda.synchronize()
+    from oracle import gates as OGt
+    masks = [(eng.h[0] > 0).cpu()]
+    for l in range(5):
+        masks += [(eng.r1[l] > 0).cpu(), (eng.h[l + 1] > 0).cpu()]
+    tape = OGt.GateTape(masks)
+    with OGt.use_tape(tape):
+        lo = torch.nn.functional.cross_entropy(om(to_oracle(Batch.from_data_list([c])))[idx], c.y[idx])
+    assert tape.done()
+    oopt.zero_grad(); lo.backward(); oopt.step()
     assert abs(eng.loss() - lo.item()) <= 1e-4 * abs(lo.item())
     og = dict(om.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values())
+    worst = 0.0
     for n, p in og.items():
-        assert_grad_close(eng.gradient(n), p.grad, gmax, f"grad {n}")
+        if n.endswith("linear.bias") or n.endswith("gin_conv.nn.0.bias") or n.endswith("gin_conv.nn.3.bias"):
+            # analytically ZERO (a bias in front of a train-mode BatchNorm): both sides hold rounding noise of a 2,708-row sum (the fp32
+            # ORACLE's was 1.3e-5 of 0.124 in one run, the HIP path's 7e-7)
+            assert eng.gradient(n).abs().max().item() <= 1e-4 * gmax and p.grad.abs().max().item() <= 1e-3 * gmax, n
+        else:
+            worst = max(worst, assert_grad_tight(eng.gradient(n), p.grad, gmax, f"grad {n}"))
+    print(f"Cora_NC engine step, shared gates: worst gradient error {worst:.2e} ({tape.flips} gates the oracle would have set differently)")
     eng.flush_counters()
     after_o, after_h = om.state_dict(), hm.state_dict()
     assert list(after_h.keys()) == keys_before
