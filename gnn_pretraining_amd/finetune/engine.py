@@ -19,10 +19,14 @@ one replay.  What changed per step -- the dropout seed -- is read from a device 
 The encoder GEMM (172 output tiles for 256 CUs) runs as three K-slices, and the one-segment BatchNorms (2,708 rows) take the medium
 regime of csrc/batchnorm.hip (one launch instead of four).  Measured (MI355X, profiles/README.md round 3): the step was NOT host-bound as
 round 2 believed -- its kernels add up to 1.43 ms (BatchNorm 0.58, GEMMs 0.56) -- so the replay (host 0.76 ms) runs at the GPU's 1.38 ms;
-a parallel graph branch for the weight-gradient GEMMs (GMP_FINETUNE_FORK=1) makes the replay itself cost 1.45 ms of host time."""
+a parallel graph branch for the weight-gradient GEMMs (GMP_FINETUNE_FORK=1) makes the replay itself cost 1.45 ms of host time.
+Second half of round 3: BatchNorm as slabs over the whole chip in one launch (gmp_bn_config.sync: 34 -> 12 us per backward launch) brought the
+kernels to 1.0 ms; the eager step with the weight-gradient GEMMs on the side stream then beats the replay (0.88 against 0.95 ms) and is the
+default; the capture stays available (GMP_FINETUNE_GRAPH=1) and tested."""
 from __future__ import annotations
 
 import ctypes as C
+import os as _os_mod
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -67,15 +71,28 @@ class NodeClassificationEngine:
         # per-layer g_u / g_z1 (+ one g_u for the encoder): the weight-gradient GEMMs read them on the side stream while the chain moves on
         self.gu_l, self.gz1_l = [f(N, H) for _ in range(Lr + 1)], [f(N, 2 * H) for _ in range(Lr)]
         self.rowdot = f(Lr, N)
-        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # the side stream must sit on a hardware queue of its own: in a process whose queues are taken (bench.py after the pre-training engine) a fresh
+        # pool stream shared the main stream's queue and the forked step took 3.98 ms instead of 0.88 -- measured, not assumed (streams.py)
+        if dev.type == "cuda":
+            from .. import streams as ST
+            self.side = ST.concurrent_streams(dev, 1)[0]
+            # main <-> side dependencies by gates (a sleeping wave on a flag word, csrc/streams.hip) instead of events where the two streams
+            # were measured on different hardware queues: a queue parked on an event wait costs the running one ~2 us per kernel boundary
+            self._gates_ok = (not ST.share_queue(torch.cuda.current_stream(dev).cuda_stream, self.side.cuda_stream)
+                              and _os_mod.environ.get("GMP_FINETUNE_GATES", "1") != "0")
+        else:
+            self.side, self._gates_ok = None, False
+        self.sync_flags = torch.zeros(64, dtype=torch.int32, device=dev)
+        self._epoch = 0
         self.side_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=dev)        # device copy of step_count for captured steps (gmp_bn_config.seed_dev)
         import os as _os
-        self.use_graph = dev.type == "cuda" and _os.environ.get("GMP_FINETUNE_GRAPH", "1") != "0"
-        # weight-gradient GEMMs as a parallel branch of the captured graph: measured SLOWER on this runtime (ROCm 7.2) -- replaying a graph
-        # with a second branch costs the host 1.45 ms per replay against 0.76 ms for the single chain (profiles/README.md round 3), and the
-        # step is then host-bound again (1.52 against 1.38 ms) -- so the capture stays on one stream; GMP_FINETUNE_FORK=1 for A/B runs
-        self.fork_wgrads = _os.environ.get("GMP_FINETUNE_FORK", "0") == "1"
+        # Default since the slab BatchNorm: launch by launch, the weight-gradient GEMMs on the side stream (0.88 ms per step; the host needs
+        # 0.55-0.68 ms for the 120 ctypes launches and keeps up).  GMP_FINETUNE_GRAPH=1: the step captured once and replayed (bitwise the
+        # same numbers, host 0.43 ms per replay, 0.95 ms per step on ONE chain: replaying a graph with a second branch costs the host 1.45 ms on
+        # this runtime -- ROCm 7.2, profiles/README.md round 3 -- so a captured step keeps its weight gradients in the chain).
+        self.use_graph = dev.type == "cuda" and _os.environ.get("GMP_FINETUNE_GRAPH", "0") == "1"
+        self.fork_wgrads = _os.environ.get("GMP_FINETUNE_FORK", "0" if self.use_graph else "1") == "1"
         self._graph, self._graph_key, self._graph_step, self._graph_seen = None, None, -1, None
         self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
@@ -205,7 +222,7 @@ class NodeClassificationEngine:
         """loss = cross_entropy(model(data)[node_indices], targets) (mean); backward; AdamW.  Nothing is read back: loss().
         Training steps with an update are replayed from a hipGraph captured at the first such call for these index tensors."""
         if not (self.use_graph and apply_update and self.model.training):
-            self._enqueue(node_indices, targets, apply_update)
+            self._enqueue(node_indices, targets, apply_update, forked=self.fork_wgrads)
             self.step_count += 1
             return
         key = (node_indices.data_ptr(), targets.data_ptr(), int(node_indices.numel()))
@@ -249,8 +266,20 @@ class NodeClassificationEngine:
         sst = side.cuda_stream if side is not None else st
         wws = self.side_ws if side is not None else self.gemm_ws
 
+        gates = side is not None and self._gates_ok and not torch.cuda.is_current_stream_capturing()
+        if gates:
+            self._epoch += 1
+        flags, epoch, nfork = self.sync_flags.data_ptr(), self._epoch, [0]
+
         def fork() -> None:                                         # the side stream may read what main has produced so far
-            if side is not None:
+            if side is None:
+                return
+            if gates:
+                k = nfork[0]
+                nfork[0] = k + 1
+                self._chk(lib.gmp_gate_open(flags + 4 * k, epoch, st), "gate open")
+                self._chk(lib.gmp_gate_wait(flags, 1 << k, epoch, flags + 4 * 63, sst), "gate wait")
+            else:
                 side.wait_stream(main)
 
         self.forward()
@@ -308,8 +337,12 @@ class NodeClassificationEngine:
                                  self.enc_mean.data_ptr(), self.enc_rstd.data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G("input_encoder.batch_norm.weight")]),
                                  _i64([self._G("input_encoder.batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn encoder bwd")
         self._wgrad(st, gu.data_ptr(), self.x.data_ptr(), "input_encoder.linear.weight", "input_encoder.linear.bias", H, self.dpad, self.dpad)
-        if side is not None:
-            main.wait_stream(side)                                  # every weight gradient is in the buffer
+        if side is not None:                                        # every weight gradient is in the buffer
+            if gates:
+                self._chk(lib.gmp_gate_open(flags + 4 * 40, epoch, sst), "gate open")
+                self._chk(lib.gmp_gate_wait(flags, 1 << 40, epoch, flags + 4 * 63, st), "gate wait")
+            else:
+                main.wait_stream(side)
         # AdamW over the flat buffer (the pre-training engine's multi-tensor kernels with one task: no projection, no clipping)
         self._chk(lib.gmp_mt_pcgrad_clip_adamw(g, self.P, 1, self.K, self.t_off.data_ptr(), self.t_len.data_ptr(), self.has.data_ptr(), _i32([0]), 1, 0, -1,
                                                self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -318,7 +351,13 @@ class NodeClassificationEngine:
                                                self.mt_ws.data_ptr(), self.mt_ws.numel(), int(apply_update), st), "adamw")
 
     def loss(self) -> float:
-        return float(self.loss_sum.item()) / max(self.num_targets, 1)
+        """Mean cross-entropy of the last step (a read-back: the one place the loop synchronises, so the gates' time-out word and the slab
+        BatchNorm's are looked at here too)."""
+        v = float(self.loss_sum.item())
+        if int(self.sync_flags[63].item()) != 0 or (self.bn_sync is not None and int(self.bn_sync[0].item()) != 0):
+            raise L.GnnmpError("fine-tune engine: a cross-stream gate or a BatchNorm slab wait timed out (streams sharing a hardware queue, "
+                               "a tool serialising kernels, or a sync buffer shared between streams): results since then are not to be trusted")
+        return v / max(self.num_targets, 1)
 
     def gradient(self, name: str) -> Tensor:
         o = self.off[name]

@@ -1,5 +1,6 @@
-"""Cora_NC fine-tune step alone (BASELINE.json configs[4]) for rocprofv3 / A-B timing: python scripts/profile_cora.py [steps] [graph|eager|graph1]
-graph1 = captured on one stream (the engine's default), graph = captured with the weight-gradient side branch, eager = launch by launch."""
+"""Cora_NC fine-tune step alone (BASELINE.json configs[4]) for rocprofv3 / A-B timing: python scripts/profile_cora.py [steps] [graph|eager|graph1|eagerfork]
+graph1 = captured on one stream, graph = captured with the weight-gradient side branch, eager = launch by launch on one stream,
+eagerfork = launch by launch with the weight-gradient GEMMs on the side stream."""
 import os
 import sys
 import time
@@ -20,8 +21,8 @@ g = S.cora_like(gen)
 model = FinetuneGNN(dev, "Cora_NC", "full_finetune")
 model.train()
 eng = NodeClassificationEngine(model, g.x, g.edge_index, dev, seed=0)
-eng.use_graph = mode != "eager"
-eng.fork_wgrads = mode == "graph"
+eng.use_graph = mode in ("graph", "graph1")
+eng.fork_wgrads = mode in ("graph", "eagerfork")
 idx = torch.randperm(g.num_nodes, generator=gen)[:140].to(dev)
 y = g.y[idx.cpu()].to(dev)
 for _ in range(20):

@@ -377,21 +377,22 @@ def test_finetune_node_classification_engine_matches_the_oracle_step():
 
 
 def test_finetune_engine_graph_replay_equals_the_eager_steps():
-    """The Cora_NC step replayed from its captured hipGraph (finetune/engine.py: one replay instead of ~65 launches, weight-gradient GEMMs on a
-    parallel branch, dropout seed read from a device word) against the same engine launching every step eagerly on one stream: dropout ON,
-    five steps, parameters / moments / running statistics / loss BITWISE equal -- replay k draws the masks of eager step k."""
+    """The Cora_NC step three ways (finetune/engine.py): replayed from its captured hipGraph (one replay instead of ~120 launches, dropout seed read
+    from a device word), launched eagerly with the weight-gradient GEMMs on the side stream (the default), and eagerly on one stream: dropout ON,
+    five steps, parameters / moments / running statistics / loss BITWISE equal -- replay k draws the masks of eager step k, and a weight
+    gradient is the same GEMM on either stream."""
     from gnn_pretraining_amd.finetune.engine import NodeClassificationEngine
     gen = torch.Generator().manual_seed(35)
     c = S.cora_like(gen)
     idx = torch.randperm(c.num_nodes, generator=gen)[:140].to(DEV)
     y = c.y[idx.cpu()].to(DEV)
     outs = []
-    for use_graph in (True, False):
+    for use_graph, fork in ((True, False), (False, True), (False, False)):
         torch.manual_seed(35)
         hm = FinetuneGNN(torch.device("cpu"), "Cora_NC", "full_finetune")
         hm.device = DEV; hm.to(DEV); hm.train()
         eng = NodeClassificationEngine(hm, c.x, c.edge_index, DEV, seed=9)
-        eng.use_graph = use_graph
+        eng.use_graph, eng.fork_wgrads = use_graph, fork
         eng.lr.mul_(30)
         losses = []
         for k in range(5):
@@ -401,10 +402,11 @@ def test_finetune_engine_graph_replay_equals_the_eager_steps():
         eng.flush_counters()
         torch.cuda.synchronize()
         outs.append((eng.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), {k: v.clone() for k, v in hm.state_dict().items()}, losses, eng.step_count))
-    a, b = outs
-    assert a[5] == b[5] == 5 and a[4] == b[4], (a[4], b[4])
+    a = outs[0]
     assert len(set(a[4])) == 5                                           # the loss moves: the steps are real
-    for i in range(3):
-        assert torch.equal(a[i], b[i])
-    for k in a[3]:
-        assert torch.equal(a[3][k], b[3][k]), k
+    for b in outs[1:]:
+        assert a[5] == b[5] == 5 and a[4] == b[4], (a[4], b[4])
+        for i in range(3):
+            assert torch.equal(a[i], b[i])
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k
