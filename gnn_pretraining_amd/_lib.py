@@ -132,6 +132,8 @@ _SIGS: Dict[str, tuple] = {
     "gmp_spin_us": (C.c_int, [i32, p]),
     "gmp_gate_wait": (C.c_int, [p, C.c_uint64, i32, p, p]),
     "gmp_gate_open": (C.c_int, [p, i32, p]),
+    "gmp_gate_open_by_next_gemm": (C.c_int, [p, i32]),
+    "gmp_gate_open_pending": (C.c_int, []),
     "gmp_gate_set_timeout": (C.c_int, [C.c_double]),
     "gmp_counter_add": (C.c_int, [p, C.c_uint64, p]),
     "gmp_aug_workspace_bytes": (sz, [i64, i64, i32]),

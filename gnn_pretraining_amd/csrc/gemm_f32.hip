@@ -521,6 +521,13 @@ void signal_on_next_gemm(int32_t* flag, int value) {
 bool signal_pending() { return t_sig_flag != nullptr; }
 }  // namespace gmp
 
+// C-ABI face of the above (gnnmp.h): the NEXT gmp_gemm_f32 / gmp_gemm_f32_grouped call of this thread opens the gate as its first workgroup starts
+extern "C" int gmp_gate_open_by_next_gemm(int32_t* flag, int value) {
+    gmp::signal_on_next_gemm(flag, value);
+    return GMP_OK;
+}
+extern "C" int gmp_gate_open_pending(void) { return gmp::signal_pending() ? 1 : 0; }
+
 extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     (void)mode;
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -271,16 +271,26 @@ class NodeClassificationEngine:
             self._epoch += 1
         flags, epoch, nfork = self.sync_flags.data_ptr(), self._epoch, [0]
 
-        def fork() -> None:                                         # the side stream may read what main has produced so far
+        def fork(by_gemm: bool = False) -> None:
+            """The side stream may read what main has produced so far.  by_gemm (gates only): the caller launches a GEMM on MAIN next, which
+            carries the signal as it starts (gmp_gate_open_by_next_gemm) -- no one-thread launch on the chain."""
             if side is None:
                 return
             if gates:
                 k = nfork[0]
                 nfork[0] = k + 1
-                self._chk(lib.gmp_gate_open(flags + 4 * k, epoch, st), "gate open")
+                if by_gemm:
+                    self._chk(lib.gmp_gate_open_by_next_gemm(flags + 4 * k, epoch), "gate open by gemm")
+                else:
+                    self._chk(lib.gmp_gate_open(flags + 4 * k, epoch, st), "gate open")
                 self._chk(lib.gmp_gate_wait(flags, 1 << k, epoch, flags + 4 * 63, sst), "gate wait")
             else:
                 side.wait_stream(main)
+
+        def flush() -> None:                                        # the GEMM that was to carry the signal launched nothing: open the gate by hand
+            if gates and lib.gmp_gate_open_pending():
+                self._chk(lib.gmp_gate_open_by_next_gemm(None, 0), "cancel")
+                self._chk(lib.gmp_gate_open(flags + 4 * (nfork[0] - 1), epoch, st), "gate open")
 
         self.forward()
         M = int(node_indices.numel())
@@ -305,6 +315,7 @@ class NodeClassificationEngine:
         gcur.zero_()
         self._chk(lib.gmp_row_fill(gcur.data_ptr(), idx, self._rows_gh.data_ptr(), M, N, H, 0, st), "scatter g_h")
         sp, one = self.seg_ptr.data_ptr(), _i32([0, 1])
+        pending_eps = None
         for l in reversed(range(GNN_NUM_LAYERS)):
             pre, layer = f"gnn_backbone.layers.{l}.", self.model.gnn_backbone.layers[l]
             gu, gz1 = self.gu_l[l], self.gz1_l[l]
@@ -313,23 +324,27 @@ class NodeClassificationEngine:
                                      P(pre + "batch_norm.bias"), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), self.stat["m2"][l].data_ptr(),
                                      self.stat["s2"][l].data_ptr(), gu.data_ptr(), g, g, one, _i64([self._G(pre + "batch_norm.weight")]),
                                      _i64([self._G(pre + "batch_norm.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn2 bwd")
-            fork()
-            self._wgrad(sst, gu.data_ptr(), self.r1[l].data_ptr(), pre + "gin_conv.nn.3.weight", pre + "gin_conv.nn.3.bias", H, 2 * H, 2 * H, wws)
+            fork(by_gemm=True)
             self._gemm(st, NN, gu.data_ptr(), P(pre + "gin_conv.nn.3.weight"), None, self.gW.data_ptr(), N, 2 * H, H, H, 2 * H, 2 * H)
+            flush()
+            if pending_eps is not None:                             # (the previous layer's aggregation backward is behind this fork too)
+                self._eps_grad(sst, pending_eps)
+                pending_eps = None
+            self._wgrad(sst, gu.data_ptr(), self.r1[l].data_ptr(), pre + "gin_conv.nn.3.weight", pre + "gin_conv.nn.3.bias", H, 2 * H, 2 * H, wws)
             bn1, cfg = layer.gin_conv.nn[1], self._cfg(True, False, 0)
             self._chk(lib.gmp_bn_bwd(self.gW.data_ptr(), self.z1[l].data_ptr(), None, sp, None, 1, N, N, 2 * H, P(pre + "gin_conv.nn.1.weight"),
                                      P(pre + "gin_conv.nn.1.bias"), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), self.stat["m1"][l].data_ptr(),
                                      self.stat["s1"][l].data_ptr(), gz1.data_ptr(), g, g, one, _i64([self._G(pre + "gin_conv.nn.1.weight")]),
                                      _i64([self._G(pre + "gin_conv.nn.1.bias")]), 1, C.byref(cfg), self.bn_ws.data_ptr(), self.bn_ws.numel(), st), "bn1 bwd")
-            fork()
-            self._wgrad(sst, gz1.data_ptr(), self.a[l].data_ptr(), pre + "gin_conv.nn.0.weight", pre + "gin_conv.nn.0.bias", 2 * H, H, H, wws)
+            fork(by_gemm=True)
             self._gemm(st, NN, gz1.data_ptr(), P(pre + "gin_conv.nn.0.weight"), None, ga.data_ptr(), N, H, 2 * H, 2 * H, H, H)
+            flush()
+            self._wgrad(sst, gz1.data_ptr(), self.a[l].data_ptr(), pre + "gin_conv.nn.0.weight", pre + "gin_conv.nn.0.bias", 2 * H, H, H, wws)
             rowdot = self.rowdot[l]
             self._chk(lib.gmp_gin_aggregate_bwd_ex(ga.data_ptr(), c.rowptr_t.data_ptr(), c.col_t.data_ptr(), P(pre + "gin_conv.eps"), self.h[l].data_ptr(),
                                                    gu.data_ptr(), gcur.data_ptr(), rowdot.data_ptr(), N, H, st), "aggregate bwd")
-            if side is not None:
-                fork()
-            self._chk(lib.gmp_group_sum_1d(rowdot.data_ptr(), 1, _i32([0, N]), _i64([self._G(pre + "gin_conv.eps")]), g, sst), "eps grad")
+            pending_eps = l                                          # eps gradient: a 5 us sum that only feeds the gradient buffer -- with the next fork
+        self._eps_grad(st, pending_eps)                             # layer 0's: on main, in front of the encoder backward
         enc, cfg = self.model.input_encoder, self._cfg(True, True, 1)
         gu = self.gu_l[GNN_NUM_LAYERS]
         self._chk(lib.gmp_bn_bwd(gcur.data_ptr(), self.z0.data_ptr(), None, sp, None, 1, N, N, H, P("input_encoder.batch_norm.weight"),
@@ -349,6 +364,10 @@ class NodeClassificationEngine:
                                                self.steps.data_ptr() if apply_update else None, self.lr.data_ptr(), self.wd.data_ptr(), 0.9, 0.999, 1e-8, 0.0,
                                                self.final_grad.data_ptr(), self.normsq.data_ptr(), self.metrics.data_ptr(), self.flags.data_ptr(),
                                                self.mt_ws.data_ptr(), self.mt_ws.numel(), int(apply_update), st), "adamw")
+
+    def _eps_grad(self, stream: int, l: int) -> None:
+        self._chk(self.lib.gmp_group_sum_1d(self.rowdot[l].data_ptr(), 1, _i32([0, self.N]), _i64([self._G(f"gnn_backbone.layers.{l}.gin_conv.eps")]),
+                                            self.grad.data_ptr(), stream), "eps grad")
 
     def loss(self) -> float:
         """Mean cross-entropy of the last step (a read-back: the one place the loop synchronises, so the gates' time-out word and the slab

@@ -416,6 +416,12 @@ int gmp_spin_us(int microseconds, gmp_stream_t stream);
  * streams on different hardware queues (gmp_streams_share_queue): in one in-order queue a gate ahead of its opener never opens. */
 int gmp_gate_wait(const int32_t* flags, uint64_t mask, int want, int32_t* err, gmp_stream_t stream);
 int gmp_gate_open(int32_t* flag, int value, gmp_stream_t stream);
+/* The same signal without a launch of its own: the NEXT gmp_gemm_f32 / gmp_gemm_f32_grouped call made by this host thread stores `value` to
+ * *flag when its first workgroup starts -- stream order has then retired everything enqueued on that GEMM's stream before it -- which takes
+ * the one-thread launch (4 us + a kernel boundary) off a critical chain (flag NULL: cancel).  gmp_gate_open_pending: 1 while a signal waits
+ * for its GEMM (a GEMM call that launched nothing leaves it pending: open the gate with gmp_gate_open then). */
+int gmp_gate_open_by_next_gemm(int32_t* flag, int value);
+int gmp_gate_open_pending(void);
 /* Time-out of the gates enqueued from now on (default: GMP_GATE_TIMEOUT_S seconds, else 120; fractions allowed).  A gate that
  * times out sets *err and lets its stream go on; the engine's data-parallel start-up check (StepEngine.verify_gates) runs
  * its probe steps with a short one so that a stream layout that cannot carry gates shows within seconds. */
