@@ -47,7 +47,8 @@ def _worker(rank, world, port, out, overlap, mode="allreduce"):
     inp, gen = _inputs(rank, eng)
     eng.step(inp, gen)
     torch.cuda.synchronize()
-    first = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu(), "final": eng.final_grad.cpu(), "normsq": eng.normsq.cpu(), "flags": eng.flags.cpu()}
+    first = {"tg": eng.task_grads.cpu(), "flat": eng.flat.cpu(), "final": eng.final_grad.cpu(), "normsq": eng.normsq.cpu(), "flags": eng.flags.cpu(),
+             "gate_err": int(eng.sync_flags[63].item()) if eng.use_gates else -1}     # 1: a cross-stream gate timed out in the first step (two processes share the GPU here)
     eng.step(inp, gen)                                                      # a second step: the events / message buffers are reused
     torch.cuda.synchronize()
     sync = eng._shard_sync_obj if mode == "sharded" else eng._packed_sync
@@ -122,7 +123,7 @@ def test_engine_dp_exchange_is_the_mean_and_replicas_stay_identical(overlap):
         again, _ = single_rank()
         rep = [torch.equal(a, b) for a, b in zip(singles, again)]
         raise AssertionError(f"{len(wrong)} of {checked} (task, tensor) pairs off the mean of the single-rank gradients; single-rank runs repeat bitwise: {rep}; "
-                             f"gates {eng.use_gates}; first: {wrong[:6]}")
+                             f"gates {eng.use_gates}; gate time-out word of the ranks' first step: {[out[r]['gate_err'] for r in range(world)]}; first: {wrong[:6]}")
     assert checked > 100
     assert torch.equal(out[0]["flat"], out[1]["flat"])                      # identical update on both ranks
     assert torch.equal(out[0]["tg"], out[1]["tg"])
