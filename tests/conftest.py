@@ -23,7 +23,9 @@ def pytest_collection_modifyitems(config, items):
         if "gpu" in item.keywords:
             item.add_marker(skip)
 
-# a cross-stream gate that can never open (a bug) should cost a test run seconds, not the two minutes a production run allows a
-# slow peer GPU (csrc/streams.hip); the engine reports a timed-out gate at its next host sync point
+# a cross-stream gate that can never open (a bug) should not cost a test run the two minutes a production run allows a slow peer GPU
+# (csrc/streams.hip); the engine reports a timed-out gate at its next host sync point.  Not TOO short: on a fresh box the first steps of a
+# process wait for code objects to page in, and the two data-parallel ranks of test_gpu_dist.py share one GPU -- with 10 s the ranks' first
+# step was seen to run past a gate twice in fourteen runs of the whole suite, always as the first command on a cold box (round 3)
 import os
-os.environ.setdefault("GMP_GATE_TIMEOUT_S", "10")
+os.environ.setdefault("GMP_GATE_TIMEOUT_S", "45")
