@@ -529,13 +529,17 @@ extern "C" int gmp_gate_open_by_next_gemm(int32_t* flag, int value) {
 extern "C" int gmp_gate_open_pending(void) { return gmp::signal_pending() ? 1 : 0; }
 
 extern "C" size_t gmp_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
-    (void)mode;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // split-K is used only when the output alone cannot fill the chip and K is long
     const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
     if (tiles >= 256 || K < 8 * BK_DEFAULT) return 0;
-    int64_t sk = (512 + tiles - 1) / tiles;
     const int64_t steps = (K + BK_DEFAULT - 1) / BK_DEFAULT;
+    // NT / NN (round 3, scripts/bench_gemm_slices.py): slices + their reduction launch LOSE wherever a third of the chip has a tile --
+    // 172 tiles: 38.4 against 33.6 us at K = 1,440, 20.4 against 14.2 at K = 512; 144 tiles, K = 256: 18.2 against 9.1 -- and win only for
+    // a handful of tiles under a long K (72 tiles, K = 1,440: 23.8 against 31.7; 40 tiles, K = 512: 12.7 against 16.4).  The weight-gradient
+    // form (TN: K = thousands of rows, a few dozen output tiles) keeps the old rule.
+    if (mode != GMP_GEMM_TN && !((tiles <= 96 && steps >= 32) || (tiles <= 48 && steps >= 16))) return 0;
+    int64_t sk = (512 + tiles - 1) / tiles;
     if (sk > steps / 2) sk = steps / 2;
     if (sk < 2) return 0;
     return (size_t)sk * M * N * sizeof(float);

@@ -16,7 +16,7 @@ Round 3: shapes, pointers and the training rows are the same every step, so the 
 (torch.cuda.CUDAGraph over the ctypes launches) and replayed: ~65 ctypes crossings + launches per step (1.35 ms, host-bound) become
 one replay.  What changed per step -- the dropout seed -- is read from a device word the graph's last node increments
 (gmp_bn_config.seed_dev, gmp_counter_add), so replay k draws exactly the masks the eager step k draws (tests/test_gpu_modules.py).
-The encoder GEMM (172 output tiles for 256 CUs) runs as three K-slices, and the one-segment BatchNorms (2,708 rows) take the medium
+The encoder GEMM (172 output tiles for 256 CUs) ran as three K-slices (38 us; unsliced since: 33), and the one-segment BatchNorms (2,708 rows) take the medium
 regime of csrc/batchnorm.hip (one launch instead of four).  Measured (MI355X, profiles/README.md round 3): the step was NOT host-bound as
 round 2 believed -- its kernels add up to 1.43 ms (BatchNorm 0.58, GEMMs 0.56) -- so the replay (host 0.76 ms) runs at the GPU's 1.38 ms;
 a parallel graph branch for the weight-gradient GEMMs (GMP_FINETUNE_FORK=1) makes the replay itself cost 1.45 ms of host time.
@@ -184,7 +184,8 @@ class NodeClassificationEngine:
         lib, N, P, c = self.lib, self.N, self._P, self.csr
         st = torch.cuda.current_stream(self.device).cuda_stream
         enc, sp = self.model.input_encoder, self.seg_ptr.data_ptr()
-        # 2,708 x 1,440 -> 256 is 172 output tiles for 256 CUs: with a workspace the GEMM runs as K-slices (gmp_gemm_f32_workspace_bytes: 3)
+        # 2,708 x 1,440 -> 256 is 172 output tiles for 256 CUs; unsliced since round 3 (three K-slices + their reduction: 38 us, one launch: 33 --
+        # gmp_gemm_f32_workspace_bytes now slices NT / NN only below ~100 tiles)
         self._gemm(st, NT, self.x.data_ptr(), P("input_encoder.linear.weight"), P("input_encoder.linear.bias"), self.z0.data_ptr(), N, H, self.dpad,
                    self.dpad, self.dpad, H, ws=self.gemm_ws)
         cfg = self._cfg(True, True, 1)
