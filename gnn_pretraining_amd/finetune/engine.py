@@ -78,10 +78,10 @@ class NodeClassificationEngine:
             self.side = ST.concurrent_streams(dev, 1)[0]
             # main <-> side dependencies by gates (a sleeping wave on a flag word, csrc/streams.hip) instead of events where the two streams
             # were measured on different hardware queues: a queue parked on an event wait costs the running one ~2 us per kernel boundary
-            self._gates_ok = (not ST.share_queue(torch.cuda.current_stream(dev).cuda_stream, self.side.cuda_stream)
-                              and _os_mod.environ.get("GMP_FINETUNE_GATES", "1") != "0")
+            own_queue = not ST.share_queue(torch.cuda.current_stream(dev).cuda_stream, self.side.cuda_stream)
+            self._gates_ok = own_queue and _os_mod.environ.get("GMP_FINETUNE_GATES", "1") != "0"
         else:
-            self.side, self._gates_ok = None, False
+            self.side, self._gates_ok, own_queue = None, False, False
         self.sync_flags = torch.zeros(64, dtype=torch.int32, device=dev)
         self._epoch = 0
         self.side_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
@@ -92,7 +92,9 @@ class NodeClassificationEngine:
         # same numbers, host 0.43 ms per replay, 0.95 ms per step on ONE chain: replaying a graph with a second branch costs the host 1.45 ms on
         # this runtime -- ROCm 7.2, profiles/README.md round 3 -- so a captured step keeps its weight gradients in the chain).
         self.use_graph = dev.type == "cuda" and _os.environ.get("GMP_FINETUNE_GRAPH", "0") == "1"
-        self.fork_wgrads = _os.environ.get("GMP_FINETUNE_FORK", "0" if self.use_graph else "1") == "1"
+        # (no queue of its own for the side stream -- every hardware queue of the process taken --: the fork would run behind main's kernels in
+        # the same in-order queue, slower than the plain chain)
+        self.fork_wgrads = _os.environ.get("GMP_FINETUNE_FORK", "0" if (self.use_graph or not own_queue) else "1") == "1"
         self._graph, self._graph_key, self._graph_step, self._graph_seen = None, None, -1, None
         self.seg_ptr = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.bn_ws = torch.empty(self.lib.gmp_bn_workspace_bytes(N, 2 * H, 1, N), dtype=torch.uint8, device=dev)
