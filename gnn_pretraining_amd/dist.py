@@ -26,7 +26,9 @@ def init_from_env(backend: Optional[str] = None) -> int:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL needs a GPU per rank ("Duplicate GPU detected" otherwise): more local ranks than devices = a functional rehearsal over gloo
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= local_world else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
