@@ -51,69 +51,112 @@ struct MtArgs {
     const int* abort;          // nullable: nonzero at run time = something upstream went wrong (a cross-stream gate timed out): no update
 };
 
-__global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
-    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
-    const int len = a.len[k], per = ((len + GCH - 1) / GCH + 3) / 4 * 4;
-    if (j * per >= len) {                       // small tensors fill only their first chunks: the rest contribute zeros
-        if (threadIdx.x < MAXT * MAXT) a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + threadIdx.x] = 0.0;
-        return;
+// ---- which (tensor, chunk) a workgroup works on ------------------------------------------------------------------------------
+// A tensor of len4 float4 is cut into count = ceil(len4 / per4) <= NCH chunks of per4 = max(ceil(len4 / NCH), MINP4) float4: the 131k-element
+// weights into 32 chunks of 4,096 elements, the ~100 biases / BatchNorm vectors / small encoders into ONE.  The grids are one-dimensional
+// and dense over those chunks (workgroup b -> the b-th chunk in tensor order, found by wave 0 with a prefix sum over the tensors' counts);
+// round 3: the first form launched NCH workgroups for EVERY tensor -- 4,160 for the s4 model, ~3,700 of them with nothing or eight
+// elements to do -- and the launches' time followed the workgroup count, not the bytes (Gram pass 25 us for 27 MB; 61 us with 64 chunks).
+constexpr int MINP4 = 1024;
+__device__ __forceinline__ int chunk_per4(int len4, int nch) { return max((len4 + nch - 1) / nch, MINP4); }
+__device__ __forceinline__ int chunk_count(int len, int nch) {
+    const int len4 = (len + 3) / 4;
+    return len4 > 0 ? (len4 + chunk_per4(len4, nch) - 1) / chunk_per4(len4, nch) : 1;
+}
+// workgroup b of a launch over tensors [k0, k1): its tensor and chunk; false = b lies beyond the last chunk (the grid is an upper bound)
+__device__ __forceinline__ bool locate_chunk(const MtArgs& a, int k0, int k1, int nch, int b, int* k_out, int* j_out) {
+    __shared__ int s_kj[2];
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) s_kj[0] = -1;
+        int base = 0;
+        for (int t0 = k0; t0 < k1; t0 += 64) {
+            const int k = t0 + lane;
+            const int cnt = k < k1 ? chunk_count(a.len[k], nch) : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            const int excl = base + incl - cnt;
+            if (cnt > 0 && b >= excl && b < excl + cnt) {
+                s_kj[0] = k;
+                s_kj[1] = b - excl;
+            }
+            base += __shfl(incl, 63, 64);
+            if (base > b) break;                             // wave-uniform
+        }
     }
-    bool has[MAXT];
+    __syncthreads();
+    *k_out = s_kj[0];
+    *j_out = s_kj[1];
+    return s_kj[0] >= 0;
+}
+
+// NT = number of tasks, a compile-time constant: the products form a fixed triangle with no run-time masks (a task that does not own the
+// tensor loads zeros), the (up to) four float4 of every task are requested together -- one memory latency per block instead of four -- and a
+// product's 64 lane partials (<= 16 elements each) fold by fp32 shuffles; waves and chunks are added in double, in a fixed order.  (Round 3:
+// 25 us for the 27 MB of an s4 step before; profiles/README.md has the new figure.  The first form masked 36 products at run time inside a four-trip load loop and
+// folded each product by six double-precision shuffle steps: nine and ten microseconds of the 25.)
+template <int NT>
+__global__ __launch_bounds__(TB) void gram_kernel(const MtArgs a) {
+    int k, j;
+    if (!locate_chunk(a, a.k0, a.k1, GCH, blockIdx.x, &k, &j)) return;
+    const int len = a.len[k], per = 4 * chunk_per4((len + 3) / 4, GCH);
+    bool has[NT];
     int nh = 0;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < NT; ++t) {
         has[t] = t < a.T && a.has[k * MAXT + t];
         nh += has[t];
     }
     if (nh < 2) return;                         // nothing to project against
     const int lo = j * per, hi = min(lo + per, (len + 3) / 4 * 4);     // slots are zero-padded to a multiple of 4 floats
     double* out = a.gram_part + ((int64_t)k * GCH + j) * (MAXT * MAXT);
-    // all MAXT x MAXT upper-triangle products with compile-time indices (runtime-indexed arrays would live in scratch)
-    float acc[MAXT * (MAXT + 1) / 2];
+    constexpr int NP = NT * (NT + 1) / 2, NW = TB / 64, IT = 4;
+    float acc[NP];
 #pragma unroll
-    for (int p = 0; p < MAXT * (MAXT + 1) / 2; ++p) acc[p] = 0.f;
+    for (int p = 0; p < NP; ++p) acc[p] = 0.f;
     const int64_t off = a.off[k];
-    for (int i = lo + 4 * threadIdx.x; i < hi; i += 4 * TB) {     // <= 16 elements per thread: fp32 partials are exact enough
-        float4 g[MAXT];
+    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += IT * 4 * TB) {     // one trip for the shared tensors (<= 4,096 elements per chunk)
+        float4 g[IT][NT];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            g[t] = has[t] ? *reinterpret_cast<const float4*>(a.tg + (int64_t)t * a.stride + off + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        int p = 0;
+        for (int u = 0; u < IT; ++u) {
+            const int i = i0 + u * 4 * TB;
 #pragma unroll
-        for (int x = 0; x < MAXT; ++x)
+            for (int t = 0; t < NT; ++t)
+                g[u][t] = (has[t] && i < hi) ? *reinterpret_cast<const float4*>(a.tg + (int64_t)t * a.stride + off + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int y = x; y < MAXT; ++y, ++p) {
-                if (!(has[x] && has[y])) continue;
-                acc[p] += g[x].x * g[y].x;
-                acc[p] += g[x].y * g[y].y;
-                acc[p] += g[x].z * g[y].z;
-                acc[p] += g[x].w * g[y].w;
-            }
+        for (int u = 0; u < IT; ++u) {
+            int p = 0;
+#pragma unroll
+            for (int x = 0; x < NT; ++x)
+#pragma unroll
+                for (int y = x; y < NT; ++y, ++p) {
+                    acc[p] += g[u][x].x * g[u][y].x;
+                    acc[p] += g[u][x].y * g[u][y].y;
+                    acc[p] += g[u][x].z * g[u][y].z;
+                    acc[p] += g[u][x].w * g[u][y].w;
+                }
+        }
     }
-    // block sum of every product: butterfly inside each wave (fixed order), one barrier, then the waves' partials in wave order
-    // -- one barrier in all, where a shared-memory tree per product took sixteen for each of the fifteen products
-    constexpr int NP = MAXT * (MAXT + 1) / 2, NW = TB / 64;
     __shared__ double sh[NW][NP];
     const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
-    {
-        int p = 0;
 #pragma unroll
-        for (int x = 0; x < MAXT; ++x)
+    for (int p = 0; p < NP; ++p) {
+        float v = acc[p];
 #pragma unroll
-            for (int y = x; y < MAXT; ++y, ++p) {
-                if (!(has[x] && has[y])) continue;        // block-uniform: only the products of tasks that own this tensor
-                double v = (double)acc[p];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (lane == 0) sh[wv][p] = v;
-            }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[wv][p] = (double)v;
     }
     __syncthreads();
     if (threadIdx.x < NP) {
         int x = 0, rem = threadIdx.x;                      // (x, y) of upper-triangle slot threadIdx.x
-        while (rem >= MAXT - x) { rem -= MAXT - x; ++x; }
+        while (rem >= NT - x) { rem -= NT - x; ++x; }
         const int y = x + rem;
-        if (has[x] && has[y]) {
+        if (a.has[k * MAXT + x] && a.has[k * MAXT + y]) {
             double v = sh[0][threadIdx.x];
 #pragma unroll
             for (int w = 1; w < NW; ++w) v += sh[w][threadIdx.x];
@@ -128,7 +171,12 @@ __global__ __launch_bounds__(64) void gram_finish_kernel(MtArgs a) {
     if (x >= a.T || y >= a.T || x > y) return;
     if (!a.has[k * MAXT + x] || !a.has[k * MAXT + y]) return;
     double s = 0.0;
-    for (int j = 0; j < GCH; ++j) s += a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + x * MAXT + y];
+    const int cnt = chunk_count(a.len[k], GCH);
+    double v[GCH];                              // all chunk partials requested together (slots past the tensor's chunk count are never written)
+#pragma unroll
+    for (int j = 0; j < GCH; ++j) v[j] = j < cnt ? a.gram_part[((int64_t)k * GCH + j) * (MAXT * MAXT) + x * MAXT + y] : 0.0;
+#pragma unroll
+    for (int j = 0; j < GCH; ++j) s += v[j];
     a.gram[((int64_t)k * MAXT + x) * MAXT + y] = s;
     a.gram[((int64_t)k * MAXT + y) * MAXT + x] = s;
 }
@@ -240,12 +288,13 @@ __global__ __launch_bounds__(64) void solve_kernel(const MtArgs a) {
 // gradients and in the optimizer state, and they stay zeros), so both sweeps below move float4.
 __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
     __shared__ float sh[TB / 64];
-    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
+    int k, j;
+    if (!locate_chunk(a, a.k0, a.k1, CH, blockIdx.x, &k, &j)) return;
     float ss = 0.f;
     if (a.flags[k]) {
         float w[MAXT];
         for (int t = 0; t < MAXT; ++t) w[t] = a.weights[k * MAXT + t];
-        const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+        const int len4 = (a.len[k] + 3) / 4, per = chunk_per4(len4, CH);
         const int lo = j * per, hi = min(lo + per, len4);
         const int64_t off = a.off[k];
         for (int i = lo + threadIdx.x; i < hi; i += TB) {
@@ -278,7 +327,8 @@ __global__ __launch_bounds__(TB) void combine_kernel(MtArgs a) {
 // bit for bit the unsharded one.
 __global__ __launch_bounds__(TB) void foreign_kernel(MtArgs a) {
     __shared__ float sh[TB / 64];
-    const int k = a.k0 + blockIdx.x, j = blockIdx.y;
+    int k, j;
+    if (!locate_chunk(a, a.k0, a.k1, CH, blockIdx.x, &k, &j)) return;
     const unsigned char* has = a.has + k * MAXT;
     int flag = a.n_order > 0 && has[a.order[0]] ? 1 : 0;                    // PCGrad emits a gradient iff the first-shuffled task has the tensor
     if (!flag && a.last_task >= 0 && has[a.last_task]) flag = 1;            // ... else the last task's raw .grad stays (gradient_surgery.py:61)
@@ -291,7 +341,7 @@ __global__ __launch_bounds__(TB) void foreign_kernel(MtArgs a) {
     }
     float ss = 0.f;
     if (flag) {
-        const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+        const int len4 = (a.len[k] + 3) / 4, per = chunk_per4(len4, CH);
         const int lo = j * per, hi = min(lo + per, len4);
         const int64_t off = a.off[k];
         for (int i = lo + threadIdx.x; i < hi; i += TB) {
@@ -314,16 +364,20 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
     __shared__ double sh[TB];
     __shared__ int shc[TB], shp[TB];
     double s = 0.0;
-    {   // float4 loads, all of a thread's in flight together: one dependent load after the other cost 8 of this launch's 12.6 us (r03a trace)
-        const float4* p4 = reinterpret_cast<const float4*>(a.partial);
-        const int n4 = a.K * CH / 4;                    // CH is a multiple of 4 and the buffer 16-byte aligned
-        constexpr int U = 8;
-        for (int i0 = threadIdx.x; i0 < n4; i0 += U * TB) {
-            float4 v[U];
+    // the chunk sums of every tensor, a thread per tensor (only the chunks the tensor has: the other slots of its row are never written); the row's
+    // CH slots are requested together (one dependent load after the other cost 8 of this launch's 12.6 us, r03a trace)
+    for (int k = threadIdx.x; k < a.K; k += TB) {
+        const int cnt = chunk_count(a.len[k], CH);
+        const float4* row = reinterpret_cast<const float4*>(a.partial + (int64_t)k * CH);      // CH is a multiple of 4 and the buffer 16-byte aligned
+        float4 v[CH / 4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = i0 + u * TB < n4 ? p4[i0 + u * TB] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < CH / 4; ++q) v[q] = 4 * q < cnt ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int u = 0; u < U; ++u) s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+        for (int q = 0; q < CH / 4; ++q) {
+            if (4 * q + 0 < cnt) s += (double)v[q].x;
+            if (4 * q + 1 < cnt) s += (double)v[q].y;
+            if (4 * q + 2 < cnt) s += (double)v[q].z;
+            if (4 * q + 3 < cnt) s += (double)v[q].w;
         }
     }
     // the conflict / projection counts ride the same tree (one thread walking the K slots one dependent load after the other was
@@ -353,7 +407,8 @@ __global__ __launch_bounds__(TB) void norm_kernel(MtArgs a) {
 }
 
 __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
-    const int k = blockIdx.x, j = blockIdx.y;
+    int k, j;
+    if (!locate_chunk(a, 0, a.K, CH, blockIdx.x, &k, &j)) return;
     if (!a.flags[k]) return;                                   // grad is None: torch skips the parameter entirely
     if (a.abort && *a.abort) return;                           // the step's inputs are not to be trusted: leave parameters and moments alone
     // clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); max_norm <= 0 disables clipping
@@ -362,7 +417,7 @@ __global__ __launch_bounds__(TB) void adamw_kernel(MtArgs a) {
     const float lr = a.lr[k], wd = a.wd[k], step = a.steps[k];
     const float bc1 = 1.f - powf(a.beta1, step), bc2 = 1.f - powf(a.beta2, step);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
-    const int len4 = (a.len[k] + 3) / 4, per = (len4 + CH - 1) / CH;
+    const int len4 = (a.len[k] + 3) / 4, per = chunk_per4(len4, CH);
     const int lo = j * per, hi = min(lo + per, len4);
     const int64_t off = a.off[k];
     auto one = [&](float g, float p, float m0, float v0, float* mo, float* vo) -> float {
@@ -435,18 +490,28 @@ extern "C" int gmp_mt_pcgrad_clip_adamw_ex(const float* task_grads, int64_t task
     a.abort = abort_flag;
     hipStream_t st = (hipStream_t)stream;
     const int nk = k_end - k_begin;
+    // upper bound of the chunk count of n tensors inside a buffer of task_stride floats: every tensor has at least one chunk, and at most one
+    // more than its float4 / MINP4 (the kernels find their chunk themselves and the surplus workgroups leave at once)
+    auto nblk = [&](int n) { return (unsigned)(task_stride / (4 * MINP4) + 2 * (int64_t)n + 1); };
     if ((phases & 1) && nk > 0) {
         if (n_order > 1) {
-            hipLaunchKernelGGL(gram_kernel, dim3(nk, GCH), dim3(TB), 0, st, a);
+            switch (num_tasks) {          // (tasks beyond a.T never own a tensor: the generic form covers any count)
+                case 2: hipLaunchKernelGGL(gram_kernel<2>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+                case 3: hipLaunchKernelGGL(gram_kernel<3>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+                case 4: hipLaunchKernelGGL(gram_kernel<4>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+                case 5: hipLaunchKernelGGL(gram_kernel<5>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+                case 6: hipLaunchKernelGGL(gram_kernel<6>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+                default: hipLaunchKernelGGL(gram_kernel<MAXT>, dim3(nblk(nk)), dim3(TB), 0, st, a); break;
+            }
             hipLaunchKernelGGL(gram_finish_kernel, dim3(nk), dim3(64), 0, st, a);
         }
         hipLaunchKernelGGL(solve_kernel, dim3((nk + 63) / 64), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(combine_kernel, dim3(nk, CH), dim3(TB), 0, st, a);
+        hipLaunchKernelGGL(combine_kernel, dim3(nblk(nk)), dim3(TB), 0, st, a);
     }
-    if ((phases & 4) && nk > 0) hipLaunchKernelGGL(foreign_kernel, dim3(nk, CH), dim3(TB), 0, st, a);
+    if ((phases & 4) && nk > 0) hipLaunchKernelGGL(foreign_kernel, dim3(nblk(nk)), dim3(TB), 0, st, a);
     if (phases & 2) {
         hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(TB), 0, st, a);
-        if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(num_tensors, CH), dim3(TB), 0, st, a);
+        if (apply_update) hipLaunchKernelGGL(adamw_kernel, dim3(nblk(num_tensors)), dim3(TB), 0, st, a);
     }
     return gmp::check_launch("mt_pcgrad_clip_adamw kernels");
 }
