@@ -6,6 +6,10 @@
 namespace gmp {
 static thread_local char g_err[512] = "";
 char* err_buf() { return g_err; }
+static thread_local int g_lane_mode = LANE_ALL;
+static thread_local hipStream_t g_lane_stream = nullptr;
+int& lane_mode() { return g_lane_mode; }
+hipStream_t& lane_stream() { return g_lane_stream; }
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

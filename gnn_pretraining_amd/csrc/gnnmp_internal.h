@@ -24,6 +24,19 @@ int fail(int code, const char* fmt, ...);
 void signal_on_next_gemm(int32_t* flag, int value);
 bool signal_pending();
 
+// Two-lane enqueue (step.hip): the pre-training step's launch sequence is walked by TWO host threads at once -- the caller takes the main
+// stream's launches, a worker thread everything else -- because one thread needs ~4 us per launch and a step has ~250 (the launcher was the
+// limiter on slower hosts; two threads launching on different streams scale 1.7x on this runtime, scripts/probe_two_threads.hip).  Both
+// threads run the SAME code; a launch (kernel, async memset / copy) on a stream the thread does not take is skipped, here, below every
+// gmp_* entry point.  Thread-local; 0 = take everything (every caller outside the step executor).
+enum { LANE_ALL = 0, LANE_ONLY = 1, LANE_ALL_BUT = 2 };
+int& lane_mode();
+hipStream_t& lane_stream();
+inline bool lane_takes(hipStream_t st) {
+    const int m = lane_mode();
+    return m == LANE_ALL || ((m == LANE_ONLY) == (st == lane_stream()));
+}
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GMP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -76,3 +89,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 }  // namespace gmp
+
+
+// every launch of the library goes through the lane filter (see gmp::lane_takes)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                        \
+    do {                                                                                                                         \
+        if (gmp::lane_takes((hipStream_t)(streamId))) hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__); \
+    } while (0)
+#define hipMemsetAsync(dst, value, bytes, stream) (gmp::lane_takes((hipStream_t)(stream)) ? hipMemsetAsync((dst), (value), (bytes), (stream)) : hipSuccess)
+#define hipMemcpyAsync(dst, src, bytes, kind, stream) (gmp::lane_takes((hipStream_t)(stream)) ? hipMemcpyAsync((dst), (src), (bytes), (kind), (stream)) : hipSuccess)
+#define hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream) \
+    (gmp::lane_takes((hipStream_t)(stream)) ? hipMemcpy2DAsync((dst), (dpitch), (src), (spitch), (width), (height), (kind), (stream)) : hipSuccess)

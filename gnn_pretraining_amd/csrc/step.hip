@@ -5,6 +5,12 @@
 #include "../../include/gnnmp_step.h"
 #include <stdlib.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "gnnmp_internal.h"
 
 namespace {
@@ -42,7 +48,9 @@ enum {
     F_EXCHANGE_DONE = 38,              // exchange stream -> main: set by the caller after its last unpack (dist.OverlappedGradSync)
     F_FWD_FORK = 39,                   // main -> the second forward stream: encoders done (split forward)
     F_FWD_JOIN = 40,                   // [2] the other forward streams -> main: their row range of the stacked forward is done
-    F_WG1_DONE = 42,                   // second weight-gradient stream -> main: everything it did for this step is done
+    F_WG1_DONE = 42,
+    F_CSR = 43,                        // aux -> main: the batch's CSR / CSC are built (two-lane enqueue: an event recorded by one host thread cannot be waited on by the other)
+    F_LPCSR = 44,                      // aux -> the link-prediction head's stream: the decoder pairs' CSR is built (likewise)                   // second weight-gradient stream -> main: everything it did for this step is done
     F_ERR = 63                         // a gate timed out
 };
 struct SyncState {                     // what gmp_step_wait_grads needs from the most recent step
@@ -51,6 +59,9 @@ struct SyncState {                     // what gmp_step_wait_grads needs from th
     uint64_t head_params_mask = 0;
 };
 SyncState g_sync;
+}  // namespace
+static void g_sync_publish(const SyncState& s) { g_sync = s; }
+namespace {
 
 bool wg1_enabled() {
     static const bool on = !(getenv("GMP_STEP_WG1") && atoi(getenv("GMP_STEP_WG1")) == 0);
@@ -332,9 +343,13 @@ int task_head_params(const gmp_step_desc& d, int ti, gmp_stream_t st, float* d1)
 
 extern "C" size_t gmp_step_desc_size(void) { return sizeof(gmp_step_desc); }
 
-extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t main_, const gmp_stream_t* task_streams, gmp_stream_t aux_) {
-    if (!dp || !task_streams) return gmp::fail(GMP_ERR_ARG, "step: null descriptor");
+namespace {
+
+// The launch sequence of one step.  `lanes`: the sequence is being walked by two host threads at once (gnnmp_internal.h lane filter: each
+// skips the launches on streams it does not take); `primary`: this thread also leaves the step's flag state behind for gmp_step_wait_grads.
+int step_body(const gmp_step_desc* dp, gmp_stream_t main_, const gmp_stream_t* task_streams, gmp_stream_t aux_, bool lanes, bool primary) {
     const gmp_step_desc& d = *dp;
+    SyncState g_sync;              // this walk's copy (shadows the global: both lanes compute the same state, the primary publishes it)
     if (d.hidden != H || d.num_tasks < 1 || d.num_tasks > GMP_STEP_MAX_TASKS || d.num_domains < 1 || d.num_domains > GMP_STEP_MAX_DOMAINS ||
         d.N <= 0 || d.S <= 0 || d.enc_groups < 0 || d.enc_groups > GMP_STEP_MAX_ENC_GROUPS)
         return gmp::fail(GMP_ERR_ARG, "step: bad sizes (N=%d S=%d tasks=%d domains=%d hidden=%d)", d.N, d.S, d.num_tasks, d.num_domains, d.hidden);
@@ -362,11 +377,12 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     // signal carried by the NEXT GEMM launched from this thread (it must be on stream s and follow immediately in host order):
     // saves the one-thread launch on a critical chain; signal_flush opens the gate itself if that GEMM turned out to be empty
     auto signal_by_gemm = [&](int flag, hipEvent_t e, hipStream_t s) {
-        if (gates) gmp::signal_on_next_gemm(d.sync_flags + flag, d.epoch);
-        else (void)hipEventRecord(e, s);
+        if (gates) {
+            if (gmp::lane_takes(s)) gmp::signal_on_next_gemm(d.sync_flags + flag, d.epoch);      // (the GEMM that carries it is this thread's to launch)
+        } else (void)hipEventRecord(e, s);
     };
     auto signal_flush = [&](int flag, hipStream_t s) -> int {
-        if (!gates || !gmp::signal_pending()) return GMP_OK;
+        if (!gates || !gmp::lane_takes(s) || !gmp::signal_pending()) return GMP_OK;
         gmp::signal_on_next_gemm(nullptr, 0);
         return gmp_gate_open(d.sync_flags + flag, d.epoch, (gmp_stream_t)s);
     };
@@ -388,7 +404,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
                                         d.csr[4], d.csr[5], d.csr_status, aux_));
     else
         GMP_TRY(gmp_csr_build(d.edge_index, N, d.E, d.csr[0], d.csr[1], d.csr[2], d.csr[3], d.csr[4], d.csr[5], d.csr_status, d.csr_ws, d.csr_ws_bytes, aux_));
-    (void)hipEventRecord(ev[1], aux);
+    if (lanes) GMP_TRY(signal(F_CSR, ev[1], aux));
+    else (void)hipEventRecord(ev[1], aux);
     int lp_task = -1;
     for (int ti = 0; ti < T; ++ti)
         if (d.task[ti].kind == GMP_TASK_LP) lp_task = ti;
@@ -401,7 +418,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             GMP_TRY(gmp_csr_build(t.lp_edges, N, t.lp_K, d.lp_csr[0], d.lp_csr[1], d.lp_csr[2], d.lp_csr[3], d.lp_csr[4], d.lp_csr[5], d.lp_csr_status,
                                   d.lp_csr_ws, d.lp_csr_ws_bytes, aux_));
     }
-    (void)hipEventRecord(ev[2], aux);
+    if (lanes) GMP_TRY(signal(F_LPCSR, ev[2], aux));
+    else (void)hipEventRecord(ev[2], aux);
 
     // ---- encoders
     GMP_TRY(gmp_encoder_fwd(d.x_all, d.x_rows, N, d.S, d.src_row, d.seg_ptr, d.seg_dom, (const uint64_t*)d.rowmask, d.tiles, d.num_tiles, d.flat,
@@ -416,7 +434,8 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
         GMP_TRY(gmp_row_gather(d.h[0], t.idx, nullptr, t.nfm_target, t.num_idx, N, H, main_));
         GMP_TRY(gmp_row_fill(d.h[0], t.idx, d.flat + d.off_mask_token, t.num_idx, N, H, 1, main_));
     }
-    (void)hipStreamWaitEvent(main, ev[1], 0);
+    if (lanes) GMP_TRY(await(F_CSR, ev[1], main));
+    else (void)hipStreamWaitEvent(main, ev[1], 0);
     if (timing) (void)hipEventRecord(phase_events()[1], main);
 
     // ---- stacked backbone forward: one pass on main, or up to three row ranges on as many streams (gnnmp_step.h fwd_cut_*)
@@ -515,7 +534,10 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
             // back by as much -- the step takes the same 1.413 ms either way)
             if ((ts == main) != (pass == 1)) continue;
             if (ts != main) GMP_TRY(await(F_FWD, ev[3], ts));
-            if (d.task[ti].kind == GMP_TASK_LP) (void)hipStreamWaitEvent(ts, ev[2], 0);
+            if (d.task[ti].kind == GMP_TASK_LP) {
+                if (lanes) GMP_TRY(await(F_LPCSR, ev[2], ts));
+                else (void)hipStreamWaitEvent(ts, ev[2], 0);
+            }
             if (timing) { (void)hipEventRecord(head_events()[3 * ti], ts); g_head_recorded[3 * ti] = true; g_head_recorded[3 * ti + 2] = false; }
             GMP_TRY(task_head_inputs(d, ti, task_streams[ti], &head_d1[ti]));
             if (timing) { (void)hipEventRecord(head_events()[3 * ti + 1], ts); g_head_recorded[3 * ti + 1] = true; }
@@ -724,7 +746,102 @@ extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t m
     }
     if (d.dp_exchange) GMP_TRY(signal(F_BWD_DONE, ev[EV_BWD_DONE], main));
     if (timing) (void)hipEventRecord(phase_events()[GMP_STEP_PHASES], main);
+    if (primary) ::g_sync_publish(g_sync);
     return GMP_OK;
+}
+
+// ---- the second enqueue thread ---------------------------------------------------------------------------------------------------
+// One worker per process, started at the first two-lane step and never joined (it sleeps on a condition variable between jobs after a short
+// spin: a step arrives every ~1.4 ms).  A job is one walk of step_body with the lane filter "everything but the main stream".
+struct LaneJob {
+    const gmp_step_desc* d;
+    gmp_stream_t main_, aux_;
+    const gmp_stream_t* task_streams;
+    int device;
+};
+class LaneWorker {
+  public:
+    void post(const LaneJob& j) {
+        job_ = j;
+        done_.store(false, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            seq_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_one();
+    }
+    int wait(char* err, size_t n) {          // spin: the worker finishes within tens of microseconds of the caller's own walk
+        while (!done_.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (rc_ && err) snprintf(err, n, "%s", err_);
+        return rc_;
+    }
+    static LaneWorker& get() {
+        static LaneWorker* w = new LaneWorker();     // leaked on purpose: the thread may outlive static destruction
+        return *w;
+    }
+
+  private:
+    LaneWorker() { std::thread([this] { run(); }).detach(); }
+    void run() {
+        unsigned seen = 0;
+        for (;;) {
+            // a step every ~1.4 ms: spin for a while, then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            while (seq_.load(std::memory_order_acquire) == seen) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    cv_.wait(lk, [&] { return seq_.load(std::memory_order_acquire) != seen; });
+                    break;
+                }
+            }
+            seen = seq_.load(std::memory_order_acquire);
+            (void)hipSetDevice(job_.device);
+            gmp::lane_mode() = gmp::LANE_ALL_BUT;
+            gmp::lane_stream() = (hipStream_t)job_.main_;
+            rc_ = step_body(job_.d, job_.main_, job_.task_streams, job_.aux_, true, false);
+            if (rc_) snprintf(err_, sizeof(err_), "%s", gmp::err_buf());
+            gmp::lane_mode() = gmp::LANE_ALL;
+            done_.store(true, std::memory_order_release);
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<unsigned> seq_{0};
+    std::atomic<bool> done_{true};
+    LaneJob job_{};
+    int rc_ = 0;
+    char err_[512] = "";
+};
+
+bool lanes_enabled() {
+    static const bool on = !(getenv("GMP_STEP_LANES") && atoi(getenv("GMP_STEP_LANES")) == 0);
+    return on;
+}
+
+}  // namespace
+
+extern "C" int gmp_pretrain_step_fwd_bwd(const gmp_step_desc* dp, gmp_stream_t main_, const gmp_stream_t* task_streams, gmp_stream_t aux_) {
+    if (!dp || !task_streams) return gmp::fail(GMP_ERR_ARG, "step: null descriptor");
+    const gmp_step_desc& d = *dp;
+    if (d.num_tasks < 1 || d.num_tasks > GMP_STEP_MAX_TASKS) return gmp::fail(GMP_ERR_ARG, "step: %d tasks", d.num_tasks);
+    // Two enqueue threads when every cross-stream dependency of the step is a gate (nothing a host thread records for the other to wait on),
+    // no phase timing, and there is a stream besides main to hand over.  GMP_STEP_LANES=0: one thread.
+    bool other = false;
+    for (int ti = 0; ti < d.num_tasks; ++ti) other = other || task_streams[ti] != main_;
+    const bool two = lanes_enabled() && d.sync_flags != nullptr && d.gu_l[0] != nullptr && d.gz1_l[0] != nullptr && !phase_timing() &&
+                     aux_ != main_ && other && gmp::lane_mode() == gmp::LANE_ALL;
+    (void)events();                // (the static event pool: made before two threads could race for it)
+    if (!two) return step_body(dp, main_, task_streams, aux_, false, true);
+    LaneWorker& w = LaneWorker::get();
+    w.post(LaneJob{dp, main_, aux_, task_streams, gmp::cur_device()});
+    gmp::lane_mode() = gmp::LANE_ONLY;
+    gmp::lane_stream() = (hipStream_t)main_;
+    const int rc0 = step_body(dp, main_, task_streams, aux_, true, true);
+    gmp::lane_mode() = gmp::LANE_ALL;
+    char err[512];
+    const int rc1 = w.wait(err, sizeof(err));
+    if (!rc0 && rc1) return gmp::fail(rc1, "%s", err);
+    return rc0;
 }
 
 // Data-parallel exchange beside the backward: `st` waits until the per-task gradients of one part of the model are final in
