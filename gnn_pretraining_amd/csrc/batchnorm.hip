@@ -331,7 +331,9 @@ __device__ __forceinline__ float4 gate_of(const BnArgs& a, float4 xh, float4 gam
 // Register-resident like the forward, but only the normalised inputs stay in registers (RPT float4): the upstream gradient is
 // read twice (second time out of L2) and the gate is recomputed.  Keeping both operands resident needed 256 VGPRs at
 // RPT = 16 -- one wave per SIMD, nothing to hide a load behind -- and made this the slowest kernel of the backward chain.
-template <int RPT, int RL = SRL, int CQT = SCQ>
+// KEEP: the gated gradient stays in registers too (no second read of g_y, no second Philox pass for the dropout gate): affordable at six
+// rows per thread (122 VGPRs, still two 512-thread workgroups per CU) -- the stacked step's segments have at most ~340 rows.
+template <int RPT, int RL = SRL, int CQT = SCQ, bool KEEP = false>
 __global__ __launch_bounds__(RL * CQT) void bn_bwd_short_kernel(BnArgs a) {
     constexpr int SRL = RL, SCQ = CQT, SCOLS = 4 * CQT;
     __shared__ float4 sh[SRL][SCQ];
@@ -347,16 +349,18 @@ __global__ __launch_bounds__(RL * CQT) void bn_bwd_short_kernel(BnArgs a) {
     float4 mean, rstd;
     stats_for(a, s, c, &mean, &rstd);
     const float4 gam = ld4(a.gamma + pgrp(a, s) + c), bet = ld4(a.beta + pgrp(a, s) + c);
-    float4 xh[RPT];
+    float4 xh[RPT], gk[KEEP ? RPT : 1];
     float4 a1 = zero4(), a2 = zero4();
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = r0 + rl + i * SRL;
         xh[i] = zero4();
+        if (KEEP) gk[i] = zero4();
         if (r < r1) {
             const int64_t off = (int64_t)r * a.C + c;
             xh[i] = mul4(sub4(load_u(a, off), mean), rstd);
             const float4 ga = mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
+            if (KEEP) gk[i] = ga;
             a1 = add4(a1, ga);
             a2 = add4(a2, mul4(ga, xh[i]));
         }
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(RL * CQT) void bn_bwd_short_kernel(BnArgs a) {
         const int r = r0 + rl + i * SRL;
         if (r < r1) {
             const int64_t off = (int64_t)r * a.C + c;
-            const float4 ga = mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
+            const float4 ga = KEEP ? gk[i] : mul4(ld4(a.gy + off), gate_of(a, xh[i], gam, bet, off >> 2));
             st4(a.y + off, bwd_input(a, ga, xh[i], s1, s2, gam, rstd, inv_n));
         }
     }
@@ -931,6 +935,10 @@ extern "C" int gmp_bn_bwd(const float* g_y, const float* x, const float* residua
             G = 0;
         }
         hipLaunchKernelGGL(bn_bwd_slab_kernel<SLAB_RPT>, dim3(S * a.slabs, C / SCOLS), blk, 0, st, a);
+    } else if (max_seg_rows <= 8 * SRL) {                                 // up to 256 rows: four rows per thread, the gated gradient kept in registers
+        hipLaunchKernelGGL((bn_bwd_short_kernel<4, 2 * SRL, SCQ, true>), dim3(S, C / SCOLS), dim3(2 * SRL * SCQ), 0, st, a);
+    } else if (max_seg_rows <= 12 * SRL) {                                // 257..384 rows (the stacked step): six rows per thread, likewise
+        hipLaunchKernelGGL((bn_bwd_short_kernel<6, 2 * SRL, SCQ, true>), dim3(S, C / SCOLS), dim3(2 * SRL * SCQ), 0, st, a);
     } else if (max_seg_rows <= SHORT_MAX) {
         GMP_BN_SHORT_LAUNCH(bn_bwd_short_kernel, max_seg_rows, dim3(S, C / SCOLS), blk, st, a, true);
     } else if (max_seg_rows <= MID_MAX) {
